@@ -1,0 +1,203 @@
+"""Generate golden vectors by executing the UNMODIFIED reference on CPU fp32.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference cannot travel to the GPU box, so its outputs are committed here
+as small .npz fixtures.  Weights are NOT stored: both sides regenerate them with
+``cotracker_amd.weights.fill_synthetic_`` (name+shape keyed, numpy RandomState).
+torch version used is recorded in every file.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from cotracker.models.core.model_utils import bilinear_sampler  # noqa: E402
+from cotracker.models.core.cotracker.cotracker3_online import CoTrackerThreeOnline, posenc  # noqa: E402
+from cotracker.models.core.cotracker.cotracker3_offline import CoTrackerThreeOffline  # noqa: E402
+from cotracker.predictor import CoTrackerPredictor, CoTrackerOnlinePredictor  # noqa: E402
+
+from cotracker_amd.weights import fill_synthetic_  # noqa: E402
+from cotracker_amd.synthetic import synthetic_video  # noqa: E402
+
+META = dict(torch_version=torch.__version__, reference="facebookresearch/co-tracker@2025-03-04")
+
+
+def save(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    out["meta"] = np.array(str(META))
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def rand_pyramid(g, B, S, C, H, W, levels=4):
+    f = torch.randn(B, S, C, H, W, generator=g)
+    f = f / f.norm(dim=2, keepdim=True)
+    pyr = [f]
+    for _ in range(levels - 1):
+        x = torch.nn.functional.avg_pool2d(pyr[-1].reshape(B * S, C, *pyr[-1].shape[-2:]), 2, stride=2)
+        pyr.append(x.reshape(B, S, C, *x.shape[-2:]))
+    return pyr
+
+
+@torch.no_grad()
+def gen_sampler():
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for tag, (D, H, W) in dict(d1=(1, 24, 32), d1b=(1, 96, 128), d5=(5, 12, 16)).items():
+        inp = torch.randn(2, 6, D, H, W, generator=g)
+        co = torch.rand(2, 40, 7, 1, 3, generator=g) * torch.tensor([D + 2.0, W + 8.0, H + 8.0]) - torch.tensor(
+            [1.0, 4.0, 4.0])
+        co[:, :12] = co[:, :12].round()  # integer coordinates (round-trip is not identity)
+        co[:, 12:16, ..., 1] = co[:, 12:16, ..., 1].round() + 0.5
+        out[f"{tag}_input"] = inp
+        out[f"{tag}_coords"] = co
+        out[f"{tag}_output"] = bilinear_sampler(inp, co.clone())
+    save("sampler.npz", **out)
+
+
+@torch.no_grad()
+def gen_ops():
+    """Stage-level goldens from the reference's own modules (small sizes)."""
+    torch.manual_seed(0)
+    model = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(96, 128)).eval()
+    fill_synthetic_(model, seed=3)
+    g = torch.Generator().manual_seed(5)
+    B, S, N, C = 1, 8, 12, 128
+    pyr = rand_pyramid(g, B, S, C, 24, 32)
+    # coordinates: inside, near border, outside, integer
+    coords = torch.rand(B, S, N, 2, generator=g) * torch.tensor([36.0, 28.0]) - 2.0
+    coords[:, :, :3] = coords[:, :, :3].round()
+    qf = torch.randint(0, S, (B, N), generator=g)
+    qc = torch.rand(B, N, 2, generator=g) * torch.tensor([31.0, 23.0])
+    out = dict(coords=coords, queried_frames=qf, queried_coords=qc)
+    sup = []
+    for i in range(4):
+        out[f"fmaps{i}"] = pyr[i]
+        _, s = model.get_track_feat(pyr[i], qf, qc / 2**i, support_radius=3)
+        sup.append(s)
+        out[f"support{i}"] = s
+        cf = model.get_correlation_feat(pyr[i], coords.view(B * S, N, 2) / 2**i)
+        tfs = s.view(B, 7, 7, N, C).permute(0, 3, 1, 2, 4)
+        vol = torch.einsum("btnhwc,bnijc->btnhwij", cf, tfs)
+        if i in (0, 3):  # keep the fixture small: volumes for the finest and coarsest level only
+            out[f"corr_volume{i}"] = vol.reshape(B, S, N, 2401)
+        out[f"corr_emb{i}"] = model.corr_mlp(vol.reshape(B * S * N, 2401)).reshape(B, S, N, 256)
+    # posenc / time embedding
+    x4 = torch.randn(5, 7, 4, generator=g) * 0.3
+    out["posenc_in"] = x4
+    out["posenc_out"] = posenc(x4, 0, 10)
+    out["time_emb"] = model.time_emb
+    for t in (5, 8, 12, 24):
+        out[f"time_emb_interp{t}"] = model.interpolate_time_embed(torch.zeros(1), t)
+    # updateformer on a random token tensor
+    x = torch.randn(B, N, S, 1110, generator=g) * 0.5
+    out["uf_x"] = x
+    out["uf_delta"] = model.updateformer(x, add_space_attn=True)
+    # full forward_window, 3 iterations, with non-zero vis/conf init
+    vis = torch.randn(B, S, N, 1, generator=g) * 0.1
+    conf = torch.randn(B, S, N, 1, generator=g) * 0.1
+    cinit = qc.reshape(B, 1, N, 2).expand(B, S, N, 2).contiguous()
+    cp, vp, fp = model.forward_window(pyr, cinit, [s.unsqueeze(1) for s in sup], vis=vis, conf=conf,
+                                      attention_mask=None, iters=3, add_space_attn=True)
+    out["fw_vis_init"], out["fw_conf_init"] = vis, conf
+    for it in range(3):
+        out[f"fw_coords{it}"] = cp[it]  # already * stride
+        out[f"fw_vis{it}"] = vp[it]
+        out[f"fw_conf{it}"] = fp[it]
+    save("ops.npz", **out)
+
+
+def _queries(g, N, T, H, W):
+    q = torch.zeros(1, N, 3)
+    q[0, :, 0] = torch.randint(0, T, (N,), generator=g).float()
+    q[0, : N // 2, 0] = 0
+    q[0, :, 1] = torch.rand(N, generator=g) * (W - 1)
+    q[0, :, 2] = torch.rand(N, generator=g) * (H - 1)
+    return q
+
+
+@torch.no_grad()
+def gen_models():
+    """Model-level goldens incl. encoder: small frames, window_len 8."""
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    # online-weights model, sliding windows (T=20 -> pad 24, 5 windows) + streaming equivalence
+    torch.manual_seed(0)
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(H, W)).eval()
+    fill_synthetic_(m, seed=1)
+    video = synthetic_video(20, H, W, seed=1234)
+    q = _queries(g, 10, 14, H, W)
+    c, v, f, _ = m(video, q, iters=4)
+    out.update(on_video=video, on_queries=q, on_coords=c, on_vis=v, on_conf=f)
+    # fmaps of the same video (so the oracle can be pinned without an encoder)
+    fm = m.fnet(2 * (video[0] / 255.0) - 1.0)
+    out["on_fnet"] = fm
+    # streaming: 8-frame chunks advancing by 4
+    m.init_video_online_processing()
+    for ind in range(0, 20 - 4, 4):
+        cs, vs, fs, _ = m(video[:, ind: ind + 8], q, iters=4, is_online=True)
+    out.update(on_stream_coords=cs, on_stream_vis=vs, on_stream_conf=fs)
+    save("model_online.npz", **out)
+
+    out = {}
+    torch.manual_seed(0)
+    m = CoTrackerThreeOffline(stride=4, corr_radius=3, window_len=8, model_resolution=(H, W)).eval()
+    fill_synthetic_(m, seed=2)
+    video = synthetic_video(12, H, W, seed=99)
+    q = _queries(g, 9, 12, H, W)
+    c, v, f, _ = m(video, q, iters=4)
+    out.update(off_video=video, off_queries=q, off_coords=c, off_vis=v, off_conf=f)
+    out["off_fnet"] = m.fnet(2 * (video[0] / 255.0) - 1.0)
+    save("model_offline.npz", **out)
+
+
+@torch.no_grad()
+def gen_predictors():
+    """Predictor-level goldens at the real model resolution (384x512 internally)."""
+    out = {}
+    video = synthetic_video(10, 96, 128, seed=7)  # predictor resizes to 384x512
+    out["video"] = video
+    torch.manual_seed(0)
+    p = CoTrackerPredictor(checkpoint=None, offline=True, window_len=60)
+    fill_synthetic_(p.model, seed=4)
+    tr, vi = p(video, grid_size=4)
+    out.update(offline_grid_tracks=tr, offline_grid_vis=vi)
+    q = torch.tensor([[[0.0, 30.0, 20.0], [3.0, 100.0, 70.0], [5.0, 64.0, 48.0]]])
+    tr, vi = p(video, queries=q)
+    out.update(queries=q, offline_q_tracks=tr, offline_q_vis=vi)
+    tr, vi = p(video, queries=q, backward_tracking=True)
+    out.update(offline_qb_tracks=tr, offline_qb_vis=vi)
+
+    torch.manual_seed(0)
+    p = CoTrackerPredictor(checkpoint=None, offline=False, window_len=8)
+    fill_synthetic_(p.model, seed=5)
+    tr, vi = p(video, grid_size=4)
+    out.update(sliding_grid_tracks=tr, sliding_grid_vis=vi)
+
+    torch.manual_seed(0)
+    p = CoTrackerOnlinePredictor(checkpoint=None, window_len=8)
+    fill_synthetic_(p.model, seed=5)
+    p(video_chunk=video, is_first_step=True, grid_size=4)
+    for ind in range(0, video.shape[1] - p.step, p.step):
+        tr, vi = p(video_chunk=video[:, ind: ind + p.step * 2])
+    out.update(online_grid_tracks=tr, online_grid_vis=vi)
+    save("predictor.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_sampler()
+    gen_ops()
+    gen_models()
+    gen_predictors()
