@@ -1,0 +1,124 @@
+"""ctypes binding of the C-ABI in include/ctk.h (libctk_hip.so, built by csrc/Makefile).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded, importing any
+op raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctk_hip.so")
+
+LEVELS = 4
+DEPTH = 3
+CORR_LD = 2432
+CORR_K = 2401
+X_LD = 1120
+X_DIM = 1110
+HID = 384
+MLP = 1536
+VIRT = 64
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("wq", "bq", "wkv", "bkv", "wo", "bo", "w1", "b1", "w2", "b2", "ctx_gamma", "ctx_beta")]
+
+
+class ModelWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("corr_fc1_w", "corr_fc1_b", "corr_fc2_w", "corr_fc2_b", "in_w", "in_bias_t",
+                                   "virtual_tokens", "head_w", "head_b")] + [
+        ("time_blocks", BlockWeights * DEPTH),
+        ("virtual2point", BlockWeights * DEPTH),
+        ("virtual_self", BlockWeights * DEPTH),
+        ("point2virtual", BlockWeights * DEPTH),
+    ]
+
+
+class WindowArgs(C.Structure):
+    _fields_ = [
+        ("S", C.c_int32), ("N", C.c_int32), ("iters", C.c_int32),
+        ("H", C.c_int32 * LEVELS), ("W", C.c_int32 * LEVELS),
+        ("fmaps", _fp * LEVELS), ("support", _fp * LEVELS),
+        ("point_mask", _fp),
+        ("coords", _fp), ("vis", _fp), ("conf", _fp),
+        ("scale_x", C.c_float), ("scale_y", C.c_float),
+        ("points_per_chunk", C.c_int32),
+    ]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", _fp), ("lda", C.c_int64), ("M", C.c_int32),
+        ("W", _fp), ("ldw", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+        ("C", _fp), ("ldc", C.c_int64),
+        ("bias", _fp),
+        ("bias_rows", _fp), ("bias_period", C.c_int32),
+        ("resid", _fp), ("ldr", C.c_int64),
+        ("act", C.c_int32),
+        ("batch", C.c_int32), ("a_bs", C.c_int64), ("c_bs", C.c_int64),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", _fp), ("q_ld", C.c_int64), ("q_bs", C.c_int64), ("q_is", C.c_int64),
+        ("k", _fp), ("v", _fp), ("kv_ld", C.c_int64), ("kv_bs", C.c_int64), ("kv_is", C.c_int64),
+        ("out", _fp), ("o_ld", C.c_int64), ("o_bs", C.c_int64), ("o_is", C.c_int64),
+        ("nbatch", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
+        ("splits", C.c_int32), ("partial", _fp),
+    ]
+
+
+# every symbol include/ctk.h declares: (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    "ctk_abi_version": (C.c_int, []),
+    "ctk_error_string": (C.c_char_p, [C.c_int]),
+    "ctk_forward_window_workspace_bytes": (C.c_int, [_P(WindowArgs), _P(C.c_size_t)]),
+    "ctk_forward_window": (C.c_int, [_P(WindowArgs), _P(ModelWeights), _fp, C.c_size_t, _fp]),
+    "ctk_corr_embed_workspace_bytes": (C.c_int, [_P(WindowArgs), _P(C.c_size_t)]),
+    "ctk_corr_embed": (C.c_int, [_P(WindowArgs), _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
+    "ctk_corr_volume": (C.c_int, [_P(WindowArgs), _fp, _fp]),
+    "ctk_assemble_tokens": (C.c_int, [_P(WindowArgs), _fp, _fp]),
+    "ctk_update_former_workspace_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
+    "ctk_update_former": (C.c_int, [C.c_int32, C.c_int32, _fp, _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
+    "ctk_tap_indices": (C.c_int, [_P(WindowArgs), _fp, _fp]),
+    "ctk_sample_patches": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, C.c_int32, _fp, _fp]),
+    "ctk_sample_support": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, _fp, _fp]),
+    "ctk_normalize_to_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
+    "ctk_avg_pool2_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
+    "ctk_gemm": (C.c_int, [_P(GemmArgs), _fp]),
+    "ctk_layernorm": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, C.c_float, _fp]),
+    "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libctk_hip.so (once) and type every exported symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C co-tracker_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ctk_abi_version() != 1:
+        raise RuntimeError("libctk_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().ctk_error_string(rc)
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else rc} (code {rc})")

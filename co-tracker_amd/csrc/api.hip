@@ -1,0 +1,319 @@
+// C-ABI orchestration: one update iteration = corr_embed -> assemble_tokens -> update_former
+// -> heads + state update, all enqueued on the caller's stream (no host sync, capturable).
+#include "ctk_common.h"
+
+int ctk_launch_corr_volume(const ctk_window_args* a, int n0, int ncount, float* out, long level_stride, int ld,
+                           hipStream_t s);
+int ctk_launch_virtual_init(const float* vt, int S, float* dst, hipStream_t s);
+int ctk_launch_heads(const float* tokens, const float* hw, const float* hb, int S, int N, float* delta, float* coords,
+                     float* vis, float* conf, hipStream_t s);
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+#define CTK_TRY(expr)        \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+int gemm(const float* A, long lda, int M, const float* W, long ldw, int N, int K, float* C, long ldc, const float* bias,
+         int act, const float* resid, long ldr, hipStream_t s, const float* bias_rows = nullptr, int period = 0,
+         int batch = 1, long a_bs = 0, long c_bs = 0) {
+  ctk_gemm_args g;
+  g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.bias_rows = bias_rows; g.bias_period = period; g.resid = resid; g.ldr = ldr; g.act = act;
+  g.batch = batch; g.a_bs = a_bs; g.c_bs = c_bs;
+  return ctk_gemm(&g, s);
+}
+
+// ---- update-former workspace carve -------------------------------------------------------
+struct UfWs {
+  float* tokens;  // [R,384]
+  float* xn;      // [R,384]
+  float* qkv;     // [R,1152]
+  float* att;     // [R,384]
+  float* hid;     // [R,1536]
+  float* partial; // attention split-K partials
+  size_t bytes;
+};
+
+int v2p_splits(int N) {
+  int s = (N + 511) / 512;  // ~512 keys per workgroup
+  if (s < 1) s = 1;
+  if (s > 32) s = 32;
+  return s;
+}
+
+UfWs carve_uf(int S, int N, void* base) {
+  const size_t R = (size_t)(N + CTK_VIRT) * S;
+  UfWs w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* r = reinterpret_cast<float*>(p + off);
+    off += align256(nfloat * sizeof(float));
+    return r;
+  };
+  w.tokens = take(R * CTK_HID);
+  w.xn = take(R * CTK_HID);
+  w.qkv = take(R * 3 * CTK_HID);
+  w.att = take(R * CTK_HID);
+  w.hid = take(R * CTK_MLP);
+  w.partial = take((size_t)v2p_splits(N) * S * CTK_HEADS * CTK_VIRT * (CTK_HEAD_DIM + 2));
+  w.bytes = off;
+  return w;
+}
+
+int attn(const float* q, long q_ld, long q_bs, long q_is, const float* k, const float* v, long kv_ld, long kv_bs,
+         long kv_is, float* out, long o_bs, long o_is, int nbatch, int n1, int n2, int splits, float* partial,
+         hipStream_t s) {
+  ctk_attn_args a;
+  a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.q_is = q_is;
+  a.k = k; a.v = v; a.kv_ld = kv_ld; a.kv_bs = kv_bs; a.kv_is = kv_is;
+  a.out = out; a.o_ld = CTK_HID; a.o_bs = o_bs; a.o_is = o_is;
+  a.nbatch = nbatch; a.n1 = n1; a.n2 = n2; a.splits = splits; a.partial = partial;
+  return ctk_attention(&a, s);
+}
+
+// residual MLP: x += fc2(gelu_tanh(fc1(LN(x))))  on rows [r0, r0+R)   (blocks.py:437 / cotracker.py:576)
+int mlp_block(const UfWs& ws, long r0, long R, const ctk_block_weights& b, hipStream_t s) {
+  float* tok = ws.tokens + r0 * CTK_HID;
+  float* xn = ws.xn + r0 * CTK_HID;
+  float* hid = ws.hid + r0 * CTK_MLP;
+  CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, s));
+  CTK_TRY(gemm(xn, CTK_HID, (int)R, b.w1, CTK_HID, CTK_MLP, CTK_HID, hid, CTK_MLP, b.b1, CTK_ACT_GELU_TANH, nullptr, 0, s));
+  CTK_TRY(gemm(hid, CTK_MLP, (int)R, b.w2, CTK_MLP, CTK_HID, CTK_MLP, tok, CTK_HID, b.b2, CTK_ACT_NONE, tok, CTK_HID, s));
+  return CTK_OK;
+}
+
+int check_block(const ctk_block_weights& b, bool cross) {
+  if (!b.wq || !b.bq || !b.wkv || !b.bkv || !b.wo || !b.bo || !b.w1 || !b.b1 || !b.w2 || !b.b2) return CTK_E_NULL;
+  if (cross && (!b.ctx_gamma || !b.ctx_beta)) return CTK_E_NULL;
+  return CTK_OK;
+}
+
+// EfficientUpdateFormer.forward (cotracker.py:483-531) on tokens already holding the input
+// projection in rows [0, N*S).
+int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
+  const long P = (long)N * S;             // point rows
+  const long V = (long)CTK_VIRT * S;      // virtual rows
+  const long R = P + V;
+  const long QL = 3 * CTK_HID;            // qkv leading dimension
+  float* tok = ws.tokens;
+  float* xn = ws.xn;
+  float* qkv = ws.qkv;
+  float* att = ws.att;
+  CTK_TRY(ctk_launch_virtual_init(w->virtual_tokens, S, tok + P * CTK_HID, s));  // cotracker.py:487-488
+
+  for (int i = 0; i < CTK_DEPTH; ++i) {
+    // ---- time attention over S for every track (incl. virtual)      cotracker.py:494-497
+    {
+      const ctk_block_weights& b = w->time_blocks[i];
+      CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(attn(qkv, QL, S, 1, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, S, 1, att, S, 1, N + CTK_VIRT, S, S, 1, nullptr, s));
+      CTK_TRY(gemm(att, CTK_HID, (int)R, b.wo, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
+      CTK_TRY(mlp_block(ws, 0, R, b, s));
+    }
+    // ---- virtual <- points cross attention                          cotracker.py:510-512
+    {
+      const ctk_block_weights& b = w->virtual2point[i];
+      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, s));   // norm1(virtual)
+      CTK_TRY(ctk_layernorm(tok, xn, P, b.ctx_gamma, b.ctx_beta, 1e-5f, s));                        // norm_context(points)
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)P, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      // batch = frame t; query i = virtual track (row P + i*S + t); key j = point (row j*S + t)
+      CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S, CTK_VIRT, N,
+                   v2p_splits(N), ws.partial, s));
+      CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, b.wo, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
+                   tok + P * CTK_HID, CTK_HID, s));
+      CTK_TRY(mlp_block(ws, P, V, b, s));
+    }
+    // ---- virtual self attention (AttnBlock over 64 virtual tracks per frame)  cotracker.py:514
+    {
+      const ctk_block_weights& b = w->virtual_self[i];
+      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S,
+                   CTK_VIRT, CTK_VIRT, 1, nullptr, s));
+      CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, b.wo, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
+                   tok + P * CTK_HID, CTK_HID, s));
+      CTK_TRY(mlp_block(ws, P, V, b, s));
+    }
+    // ---- points <- virtual cross attention                          cotracker.py:515-517
+    {
+      const ctk_block_weights& b = w->point2virtual[i];
+      CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, s));                                              // norm1(points)
+      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, s));           // norm_context(virtual)
+      CTK_TRY(gemm(xn, CTK_HID, (int)P, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s));
+      CTK_TRY(gemm(att, CTK_HID, (int)P, b.wo, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
+      CTK_TRY(mlp_block(ws, 0, P, b, s));
+    }
+  }
+  return CTK_OK;
+}
+
+int check_weights(const ctk_model_weights* w) {
+  if (!w) return CTK_E_NULL;
+  if (!w->in_w || !w->in_bias_t || !w->virtual_tokens || !w->head_w || !w->head_b) return CTK_E_NULL;
+  for (int i = 0; i < CTK_DEPTH; ++i) {
+    CTK_TRY(check_block(w->time_blocks[i], false));
+    CTK_TRY(check_block(w->virtual2point[i], true));
+    CTK_TRY(check_block(w->virtual_self[i], false));
+    CTK_TRY(check_block(w->point2virtual[i], true));
+  }
+  return CTK_OK;
+}
+
+int input_projection(int S, int N, const float* x, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
+  // tokens = input_transform(x + time_emb)   (cotracker3_online.py:247, cotracker.py:484)
+  return gemm(x, CTK_X_LD, N * S, w->in_w, CTK_X_LD, CTK_HID, CTK_X_LD, ws.tokens, CTK_HID, nullptr, CTK_ACT_NONE, nullptr, 0,
+              s, w->in_bias_t, S);
+}
+
+// ---- corr_embed workspace -------------------------------------------------------------------
+struct CorrWs {
+  float* vol;  // [4][chunk*S][2432]
+  float* h1;   // [4*chunk*S][384]
+  size_t bytes;
+  int chunk;
+};
+
+int corr_chunk_points(const ctk_window_args* a) {
+  int c = a->points_per_chunk > 0 ? a->points_per_chunk : a->N;
+  if (c > a->N) c = a->N;
+  return c;
+}
+
+CorrWs carve_corr(const ctk_window_args* a, void* base) {
+  CorrWs w;
+  w.chunk = corr_chunk_points(a);
+  const size_t rows = (size_t)w.chunk * a->S;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  w.vol = reinterpret_cast<float*>(p + off);
+  off += align256(rows * CTK_LEVELS * CTK_CORR_LD * sizeof(float));
+  w.h1 = reinterpret_cast<float*>(p + off);
+  off += align256(rows * CTK_LEVELS * CTK_HID * sizeof(float));
+  w.bytes = off;
+  return w;
+}
+
+int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* x, const CorrWs& ws, hipStream_t s) {
+  if (!w->corr_fc1_w || !w->corr_fc1_b || !w->corr_fc2_w || !w->corr_fc2_b) return CTK_E_NULL;
+  for (int n0 = 0; n0 < a->N; n0 += ws.chunk) {
+    const int cnt = (a->N - n0 < ws.chunk) ? a->N - n0 : ws.chunk;
+    const long rows = (long)cnt * a->S;
+    CTK_TRY(ctk_launch_corr_volume(a, n0, cnt, ws.vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
+    // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
+    CTK_TRY(gemm(ws.vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), w->corr_fc1_w, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, ws.h1, CTK_HID,
+                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s));
+    // corr_mlp.fc2, one batch per level, written into x[n*S+t][l*256 ...]   (torch.cat :209)
+    CTK_TRY(gemm(ws.h1, CTK_HID, (int)rows, w->corr_fc2_w, CTK_HID, 256, CTK_HID, x + (long)n0 * a->S * CTK_X_LD + CTK_X_CORR,
+                 CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256));
+  }
+  return CTK_OK;
+}
+
+int check_window(const ctk_window_args* a) {
+  if (!a) return CTK_E_NULL;
+  if (a->S <= 0 || a->N <= 0 || a->iters < 0) return CTK_E_SHAPE;
+  if ((long)(a->N + CTK_VIRT) * a->S > 2000000000L / CTK_MLP * 64) return CTK_E_SHAPE;
+  return CTK_OK;
+}
+
+}  // namespace
+
+extern "C" int ctk_abi_version(void) { return CTK_ABI_VERSION; }
+
+extern "C" const char* ctk_error_string(int code) {
+  switch (code) {
+    case CTK_OK: return "ok";
+    case CTK_E_NULL: return "required pointer is NULL";
+    case CTK_E_SHAPE: return "unsupported shape";
+    case CTK_E_ALIGN: return "pointer or leading dimension not 16-byte aligned";
+    case CTK_E_WORKSPACE: return "workspace too small";
+    default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown error";
+  }
+}
+
+extern "C" int ctk_update_former_workspace_bytes(int32_t S, int32_t N, size_t* out_bytes) {
+  if (!out_bytes) return CTK_E_NULL;
+  if (S <= 0 || N <= 0) return CTK_E_SHAPE;
+  *out_bytes = carve_uf(S, N, nullptr).bytes;
+  return CTK_OK;
+}
+
+extern "C" int ctk_update_former(int32_t S, int32_t N, const float* x, const ctk_model_weights* w, float* delta,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !delta || !workspace) return CTK_E_NULL;
+  if (S <= 0 || N <= 0) return CTK_E_SHAPE;
+  CTK_TRY(check_weights(w));
+  if (!ctk_aligned16(workspace)) return CTK_E_ALIGN;
+  const UfWs ws = carve_uf(S, N, workspace);
+  if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  CTK_TRY(input_projection(S, N, x, w, ws, s));
+  CTK_TRY(run_transformer(S, N, w, ws, s));
+  return ctk_launch_heads(ws.tokens, w->head_w, w->head_b, S, N, delta, nullptr, nullptr, nullptr, s);
+}
+
+extern "C" int ctk_corr_embed_workspace_bytes(const ctk_window_args* a, size_t* out_bytes) {
+  if (!out_bytes) return CTK_E_NULL;
+  CTK_TRY(check_window(a));
+  *out_bytes = carve_corr(a, nullptr).bytes;
+  return CTK_OK;
+}
+
+extern "C" int ctk_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* x, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  CTK_TRY(check_window(a));
+  if (!w || !x || !workspace) return CTK_E_NULL;
+  if (!ctk_aligned16(workspace) || !ctk_aligned16(x)) return CTK_E_ALIGN;
+  const CorrWs ws = carve_corr(a, workspace);
+  if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
+  return run_corr_embed(a, w, x, ws, static_cast<hipStream_t>(stream));
+}
+
+// Workspace of a whole window: x | update-former buffers | correlation buffers
+extern "C" int ctk_forward_window_workspace_bytes(const ctk_window_args* a, size_t* out_bytes) {
+  if (!out_bytes) return CTK_E_NULL;
+  CTK_TRY(check_window(a));
+  size_t total = align256((size_t)a->N * a->S * CTK_X_LD * sizeof(float));
+  total += carve_uf(a->S, a->N, nullptr).bytes;
+  total += carve_corr(a, nullptr).bytes;
+  *out_bytes = total;
+  return CTK_OK;
+}
+
+extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weights* w, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  CTK_TRY(check_window(a));
+  CTK_TRY(check_weights(w));
+  if (!workspace || !a->coords || !a->vis || !a->conf) return CTK_E_NULL;
+  if (!ctk_aligned16(workspace)) return CTK_E_ALIGN;
+  size_t need = 0;
+  CTK_TRY(ctk_forward_window_workspace_bytes(a, &need));
+  if (need > workspace_bytes) return CTK_E_WORKSPACE;
+  char* base = static_cast<char*>(workspace);
+  float* x = reinterpret_cast<float*>(base);
+  size_t off = align256((size_t)a->N * a->S * CTK_X_LD * sizeof(float));
+  const UfWs uws = carve_uf(a->S, a->N, base + off);
+  off += uws.bytes;
+  const CorrWs cws = carve_corr(a, base + off);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int it = 0; it < a->iters; ++it) {                       // cotracker3_online.py:187
+    CTK_TRY(run_corr_embed(a, w, x, cws, s));                   // :190-210
+    CTK_TRY(ctk_assemble_tokens(a, x, s));                      // :212-245
+    CTK_TRY(input_projection(a->S, a->N, x, w, uws, s));        // :247 + cotracker.py:484
+    CTK_TRY(run_transformer(a->S, a->N, w, uws, s));            // :250
+    CTK_TRY(ctk_launch_heads(uws.tokens, w->head_w, w->head_b, a->S, a->N, nullptr, a->coords, a->vis, a->conf, s));  // :252-259
+  }
+  return CTK_OK;
+}

@@ -1,0 +1,175 @@
+// Row-wise kernels of the update iteration: LayerNorm, token assembly (posenc), virtual-token
+// broadcast and the output heads fused with the (coords, vis, conf) state update.
+#include "ctk_common.h"
+
+namespace {
+
+// ---- LayerNorm over 384 channels: one wavefront per row, 6 values per lane ----------------
+// nn.LayerNorm(384, elementwise_affine=False, eps=1e-6)  blocks.py:411,416 / cotracker.py:539,549
+// nn.LayerNorm(384) (affine, eps=1e-5)                    cotracker.py:540 (norm_context)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y, long R, const float* gamma,
+                                                         const float* beta, float eps) {
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* xr = x + row * CTK_HID;
+  float2 v[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const float2*>(xr + j * 128 + lane * 2);
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) s += v[j].x + v[j].y;
+  const float mean = ctk_wave_sum(s) * (1.0f / CTK_HID);
+  float q = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    v[j].x -= mean;
+    v[j].y -= mean;
+    q += v[j].x * v[j].x + v[j].y * v[j].y;
+  }
+  const float var = ctk_wave_sum(q) * (1.0f / CTK_HID);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  float* yr = y + row * CTK_HID;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = j * 128 + lane * 2;
+    float2 o = make_float2(v[j].x * rstd, v[j].y * rstd);
+    if (gamma) {
+      o.x = o.x * gamma[c] + beta[c];
+      o.y = o.y * gamma[c + 1] + beta[c + 1];
+    }
+    *reinterpret_cast<float2*>(yr + c) = o;
+  }
+}
+
+// ---- token assembly: x[n*S+t][1024..1119] = [vis, conf, posenc(rel fwd/bwd coords), 0-pad] ---
+// cotracker3_online.py:212-245 and posenc :19-39.  The time embedding (:247) is folded into the
+// input projection's per-frame bias (ctk_model_weights.in_bias_t).
+__global__ void assemble_kernel(const float* coords, const float* vis, const float* conf, int S, int N, float scale_x,
+                                float scale_y, float* x) {
+  constexpr int EW = CTK_X_LD - CTK_X_VIS;  // 96 columns written per row
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)S * N * EW;
+  if (i >= total) return;
+  const int e = i % EW;
+  const long row = i / EW;  // n*S + t
+  const int t = row % S;
+  const int n = row / S;
+  float out;
+  if (e == 0) {
+    out = vis[(long)t * N + n];
+  } else if (e == 1) {
+    out = conf[(long)t * N + n];
+  } else if (e >= 2 + 84) {
+    out = 0.0f;
+  } else {
+    const int k = e - 2;  // posenc element 0..83
+    int comp, deg;
+    bool shift = false;
+    if (k < 4) { comp = k; deg = -1; }
+    else if (k < 44) { comp = (k - 4) & 3; deg = (k - 4) >> 2; }
+    else { comp = (k - 44) & 3; deg = (k - 44) >> 2; shift = true; }
+    // comp 0,1 = forward (c[t]-c[t+1]) x,y ; comp 2,3 = backward (c[t]-c[t-1]) x,y
+    const int axis = comp & 1;
+    const bool fwd = comp < 2;
+    const int tn = fwd ? t + 1 : t - 1;
+    float rel = 0.0f;
+    if (tn >= 0 && tn < S) rel = __fsub_rn(coords[((long)t * N + n) * 2 + axis], coords[((long)tn * N + n) * 2 + axis]);
+    rel = __fdiv_rn(rel, axis == 0 ? scale_x : scale_y);
+    if (deg < 0) {
+      out = rel;
+    } else {
+      float a = __fmul_rn(rel, (float)(1 << deg));
+      if (shift) a = __fadd_rn(a, 1.57079637050628662109375f);  // f32(0.5*pi)
+      out = sinf(a);
+    }
+  }
+  x[row * CTK_X_LD + CTK_X_VIS + e] = out;
+}
+
+// ---- virtual tokens: tokens[(N+v)*S + t] = virual_tracks[v]   (cotracker.py:487-488) --------
+__global__ void virtual_init_kernel(const float* vt, int S, float* dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index over 64*S*96
+  const long total = (long)CTK_VIRT * S * (CTK_HID / 4);
+  if (i >= total) return;
+  const int c4 = i % (CTK_HID / 4);
+  const int v = i / ((long)(CTK_HID / 4) * S);
+  reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(vt)[v * (CTK_HID / 4) + c4];
+}
+
+// ---- heads: delta = tokens @ [flow_head; vis_conf_head]^T + b  (cotracker.py:526-529) -------
+// optionally fused with coords += d[:2]; vis += d[2]; conf += d[3] (cotracker3_online.py:252-259)
+__global__ __launch_bounds__(256) void heads_kernel(const float* tokens, const float* hw, const float* hb, int S, int N,
+                                                     float* delta, float* coords, float* vis, float* conf) {
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // n*S + t
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)S * N) return;
+  const float* xr = tokens + row * CTK_HID;
+  float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = j * 128 + lane * 2;
+    const float2 v = *reinterpret_cast<const float2*>(xr + c);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float2 w = *reinterpret_cast<const float2*>(hw + o * CTK_HID + c);
+      d[o] += v.x * w.x + v.y * w.y;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) d[o] = ctk_wave_sum(d[o]) + hb[o];
+  if (lane == 0) {
+    if (delta) {
+      f32x4 t = {d[0], d[1], d[2], d[3]};
+      *reinterpret_cast<f32x4*>(delta + row * 4) = t;
+    }
+    if (coords) {
+      const int t = row % S;
+      const int n = row / S;
+      const long sn = (long)t * N + n;
+      coords[sn * 2] += d[0];
+      coords[sn * 2 + 1] += d[1];
+      vis[sn] += d[2];
+      conf[sn] += d[3];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ctk_layernorm(const float* x, float* y, int64_t R, const float* gamma, const float* beta, float eps,
+                             void* stream) {
+  if (!x || !y) return CTK_E_NULL;
+  if (R <= 0) return CTK_E_SHAPE;
+  if ((gamma == nullptr) != (beta == nullptr)) return CTK_E_NULL;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     y, (long)R, gamma, beta, eps);
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}
+
+extern "C" int ctk_assemble_tokens(const ctk_window_args* a, float* x, void* stream) {
+  if (!a || !a->coords || !a->vis || !a->conf || !x) return CTK_E_NULL;
+  if (a->S <= 0 || a->N <= 0 || !(a->scale_x > 0.f) || !(a->scale_y > 0.f)) return CTK_E_SHAPE;
+  const long total = (long)a->S * a->N * (CTK_X_LD - CTK_X_VIS);
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a->coords, a->vis, a->conf, a->S, a->N, a->scale_x, a->scale_y, x);
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}
+
+int ctk_launch_virtual_init(const float* vt, int S, float* dst, hipStream_t s) {
+  const long total = (long)CTK_VIRT * S * (CTK_HID / 4);
+  hipLaunchKernelGGL(virtual_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, vt, S, dst);
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}
+
+int ctk_launch_heads(const float* tokens, const float* hw, const float* hb, int S, int N, float* delta, float* coords,
+                     float* vis, float* conf, hipStream_t s) {
+  const long rows = (long)S * N;
+  hipLaunchKernelGGL(heads_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tokens, hw, hb, S, N, delta, coords,
+                     vis, conf);
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}

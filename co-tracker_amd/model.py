@@ -1,0 +1,390 @@
+"""CoTracker3 tracker models on the MI355X hot path.
+
+Host-side mirror of the reference's model interface:
+  CoTrackerThreeOnline   <- cotracker/models/core/cotracker/cotracker3_online.py:159-541
+  CoTrackerThreeOffline  <- cotracker/models/core/cotracker/cotracker3_offline.py:15-233
+Same constructor kwargs, attributes (model_resolution, window_len, stride), ``forward``
+signature / return tuple, online-state methods and -- crucially -- the same ``state_dict`` key
+set, so reference checkpoints load unchanged and a reference ``CoTrackerPredictor`` can have its
+``.model`` swapped for one of these.
+
+The CNN encoder runs on PyTorch-ROCm; everything after it (feature normalisation + pyramid,
+support sampling, and the 6x iterative update: correlation sampling, corr MLP, token
+assembly, EfficientUpdateFormer, state update) runs in the HIP library through
+``cotracker_amd.ops``.  Window scheduling and online state are Python glue, as in the reference.
+Inference only (``is_train`` must be False).
+"""
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .encoder import BasicEncoder
+
+
+# ------------------------------------------------------------------------------------------
+# parameter containers: same names / shapes as the reference modules, no forward of their own
+# ------------------------------------------------------------------------------------------
+class _Lin(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.zeros(fout))
+        nn.init.xavier_uniform_(self.weight)  # cotracker.py:465-469
+
+
+class _Mlp(nn.Module):  # blocks.py:40-76
+    def __init__(self, fin, hidden, fout):
+        super().__init__()
+        self.fc1 = _Lin(fin, hidden)
+        self.fc2 = _Lin(hidden, fout)
+
+
+class _Attn(nn.Module):  # blocks.py:365-377
+    def __init__(self, dim=384):
+        super().__init__()
+        self.to_q = _Lin(dim, dim)
+        self.to_kv = _Lin(dim, 2 * dim)
+        self.to_out = _Lin(dim, dim)
+
+
+class _AttnBlock(nn.Module):  # blocks.py:401-424 (both LayerNorms are parameter-free)
+    def __init__(self, dim=384, ratio=4):
+        super().__init__()
+        self.attn = _Attn(dim)
+        self.mlp = _Mlp(dim, dim * ratio, dim)
+
+
+class _Affine(nn.Module):  # nn.LayerNorm(384) parameters (cotracker.py:540)
+    def __init__(self, dim=384):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _CrossBlock(nn.Module):  # cotracker.py:534-557
+    def __init__(self, dim=384, ratio=4):
+        super().__init__()
+        self.norm_context = _Affine(dim)
+        self.cross_attn = _Attn(dim)
+        self.mlp = _Mlp(dim, dim * ratio, dim)
+
+
+class _UpdateFormerParams(nn.Module):  # cotracker.py:387-462
+    def __init__(self, input_dim=1110, hidden=384, depth=3, num_virtual_tracks=64):
+        super().__init__()
+        self.input_transform = _Lin(input_dim, hidden)
+        self.flow_head = _Lin(hidden, 2)
+        self.vis_conf_head = _Lin(hidden, 2)
+        nn.init.trunc_normal_(self.flow_head.weight, std=0.001)
+        nn.init.trunc_normal_(self.vis_conf_head.weight, std=0.001)
+        self.virual_tracks = nn.Parameter(torch.randn(1, num_virtual_tracks, 1, hidden))  # (sic) reference key
+        self.time_blocks = nn.ModuleList([_AttnBlock(hidden) for _ in range(depth)])
+        self.space_virtual_blocks = nn.ModuleList([_AttnBlock(hidden) for _ in range(depth)])
+        self.space_point2virtual_blocks = nn.ModuleList([_CrossBlock(hidden) for _ in range(depth)])
+        self.space_virtual2point_blocks = nn.ModuleList([_CrossBlock(hidden) for _ in range(depth)])
+
+
+def sincos_time_embed(dim: int, window_len: int) -> torch.Tensor:
+    """get_1d_sincos_pos_embed_from_grid on linspace(0, W-1, W) (embeddings.py:59-84) -> [1,W,dim]."""
+    omega = torch.arange(dim // 2, dtype=torch.double) / (dim / 2.0)
+    omega = 1.0 / 10000 ** omega
+    pos = torch.linspace(0, window_len - 1, window_len).double()
+    out = torch.einsum("m,d->md", pos, omega)
+    return torch.cat([torch.sin(out), torch.cos(out)], dim=1)[None].float()
+
+
+# ------------------------------------------------------------------------------------------
+# device-side packed weights (the ctk_model_weights struct of include/ctk.h)
+# ------------------------------------------------------------------------------------------
+class PackedWeights:
+    """Contiguous fp32 device copies in the layouts the C-ABI wants, plus the ctypes struct."""
+
+    def __init__(self, model: "CoTrackerThreeBase", device):
+        sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in model.state_dict().items()}
+        self.device = device
+        self.keep: List[torch.Tensor] = []
+        self.time_emb = sd["time_emb"]  # [1,W,1110], reference column order
+        st = L.ModelWeights()
+
+        def hold(t: torch.Tensor) -> int:
+            t = t.contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        fc1 = torch.zeros(384, L.CORR_LD, device=device)
+        fc1[:, : L.CORR_K] = sd["corr_mlp.fc1.weight"]
+        st.corr_fc1_w = hold(fc1)
+        st.corr_fc1_b = hold(sd["corr_mlp.fc1.bias"])
+        st.corr_fc2_w = hold(sd["corr_mlp.fc2.weight"])
+        st.corr_fc2_b = hold(sd["corr_mlp.fc2.bias"])
+
+        u = "updateformer."
+        w_ref = sd[u + "input_transform.weight"]  # columns: [vis, conf, corr(1024), posenc(84)]
+        self.in_w_ref = w_ref
+        self.in_b = sd[u + "input_transform.bias"]
+        in_w = torch.zeros(384, L.X_LD, device=device)
+        in_w[:, 0:1024] = w_ref[:, 2:1026]
+        in_w[:, 1024:1026] = w_ref[:, 0:2]
+        in_w[:, 1026:1110] = w_ref[:, 1026:1110]
+        st.in_w = hold(in_w)
+        st.virtual_tokens = hold(sd[u + "virual_tracks"].reshape(64, 384))
+        st.head_w = hold(torch.cat([sd[u + "flow_head.weight"], sd[u + "vis_conf_head.weight"]], dim=0))
+        st.head_b = hold(torch.cat([sd[u + "flow_head.bias"], sd[u + "vis_conf_head.bias"]], dim=0))
+
+        def block(prefix: str, attn_name: str, cross: bool) -> L.BlockWeights:
+            b = L.BlockWeights()
+            a = f"{prefix}{attn_name}."
+            b.wq, b.bq = hold(sd[a + "to_q.weight"]), hold(sd[a + "to_q.bias"])
+            b.wkv, b.bkv = hold(sd[a + "to_kv.weight"]), hold(sd[a + "to_kv.bias"])
+            b.wo, b.bo = hold(sd[a + "to_out.weight"]), hold(sd[a + "to_out.bias"])
+            b.w1, b.b1 = hold(sd[prefix + "mlp.fc1.weight"]), hold(sd[prefix + "mlp.fc1.bias"])
+            b.w2, b.b2 = hold(sd[prefix + "mlp.fc2.weight"]), hold(sd[prefix + "mlp.fc2.bias"])
+            if cross:
+                b.ctx_gamma = hold(sd[prefix + "norm_context.weight"])
+                b.ctx_beta = hold(sd[prefix + "norm_context.bias"])
+            return b
+
+        for i in range(L.DEPTH):
+            st.time_blocks[i] = block(f"{u}time_blocks.{i}.", "attn", False)
+            st.virtual_self[i] = block(f"{u}space_virtual_blocks.{i}.", "attn", False)
+            st.virtual2point[i] = block(f"{u}space_virtual2point_blocks.{i}.", "cross_attn", True)
+            st.point2virtual[i] = block(f"{u}space_point2virtual_blocks.{i}.", "cross_attn", True)
+        self.struct = st
+        self._bias_t = {}
+
+    def time_embed(self, S: int) -> torch.Tensor:
+        """interpolate_time_embed (cotracker3_online.py:145-156) -> [S,1110] reference column order."""
+        te = self.time_emb
+        if S != te.shape[1]:
+            te = F.interpolate(te.permute(0, 2, 1), size=S, mode="linear").permute(0, 2, 1)
+        return te[0]
+
+    def struct_for(self, S: int) -> L.ModelWeights:
+        """Struct whose in_bias_t folds the S-frame time embedding into the input projection:
+        input_transform(x + e_t) = W x + (W e_t + b)   (cotracker3_online.py:247 + cotracker.py:484)."""
+        if S not in self._bias_t:
+            te = self.time_embed(S).double()
+            bias_t = (te @ self.in_w_ref.double().t() + self.in_b.double()).float().contiguous()
+            self._bias_t[S] = bias_t
+        self.struct.in_bias_t = self._bias_t[S].data_ptr()
+        return self.struct
+
+
+# ------------------------------------------------------------------------------------------
+# models
+# ------------------------------------------------------------------------------------------
+class CoTrackerThreeBase(nn.Module):
+    """Constructor mirrors cotracker3_online.py:43-92."""
+
+    def __init__(self, window_len=8, stride=4, corr_radius=3, corr_levels=4, num_virtual_tracks=64,
+                 model_resolution=(384, 512), add_space_attn=True, linear_layer_for_vis_conf=True):
+        super().__init__()
+        if (corr_radius, corr_levels, num_virtual_tracks) != (3, 4, 64) or not add_space_attn \
+                or not linear_layer_for_vis_conf:
+            raise NotImplementedError("HIP path is specialised to corr_radius=3, corr_levels=4, 64 virtual tracks, "
+                                      "space attention on (build_cotracker.py:31-38)")
+        self.window_len = window_len
+        self.stride = stride
+        self.corr_radius = corr_radius
+        self.corr_levels = corr_levels
+        self.hidden_dim = 256
+        self.latent_dim = 128
+        self.num_virtual_tracks = num_virtual_tracks
+        self.model_resolution = model_resolution
+        self.input_dim = 1110
+        self.linear_layer_for_vis_conf = linear_layer_for_vis_conf
+        self.fnet = BasicEncoder(input_dim=3, output_dim=self.latent_dim, stride=stride)
+        self.updateformer = _UpdateFormerParams(self.input_dim, 384, 3, num_virtual_tracks)
+        self.corr_mlp = _Mlp(49 * 49, 384, 256)
+        self.register_buffer("time_emb", sincos_time_embed(self.input_dim, window_len))
+        self._packed: Optional[PackedWeights] = None
+        self.max_corr_rows = 262144  # (point,frame) rows of correlation volume resident at once (~10 GB)
+
+    # -- weights ------------------------------------------------------------------------
+    def load_state_dict(self, *args, **kwargs):
+        self._packed = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def packed(self, device) -> PackedWeights:
+        if self._packed is None or self._packed.device != device:
+            self._packed = PackedWeights(self, device)
+        return self._packed
+
+    def invalidate_packed_weights(self):
+        """Call after mutating parameters in place (e.g. weights.fill_synthetic_)."""
+        self._packed = None
+
+    # -- shared pieces ------------------------------------------------------------------
+    def _scale_xy(self):
+        return (self.model_resolution[1] / self.stride, self.model_resolution[0] / self.stride)
+
+    def _encode(self, frames: torch.Tensor, chunk: int) -> torch.Tensor:
+        """frames [T,3,H,W] in 0..255 -> L2-normalised NHWC level-0 features [T,H/4,W/4,128]."""
+        outs = []
+        for t0 in range(0, frames.shape[0], chunk):
+            x = 2 * (frames[t0:t0 + chunk] / 255.0) - 1.0  # cotracker3_online.py:320
+            outs.append(ops.normalize_to_nhwc(self.fnet(x).float().contiguous()))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def _support(self, pyr, frames_f: torch.Tensor, qcoords: torch.Tensor):
+        return [ops.sample_support(pyr[l], frames_f, (qcoords / 2 ** l).contiguous()) for l in range(self.corr_levels)]
+
+    def _check_inputs(self, video, queries, is_train):
+        if is_train:
+            raise NotImplementedError("inference-only implementation (training is out of scope)")
+        if not video.is_cuda:
+            raise RuntimeError("cotracker_amd runs on an MI355X GPU only: move the model and inputs to 'cuda'. "
+                               "There is no CPU path.")
+        B, T, C, H, W = video.shape
+        assert H % self.stride == 0 and W % self.stride == 0
+        assert queries.shape[0] == B and queries.shape[2] == 3
+        return B, T, H, W
+
+
+class CoTrackerThreeOnline(CoTrackerThreeBase):
+    """Sliding-window / streaming tracker (cotracker3_online.py:159-541)."""
+
+    def init_video_online_processing(self):  # cotracker3_online.py:163-169
+        self.online_ind = 0
+        self.online_track_feat = [None] * self.corr_levels  # unused by v3, kept for API parity
+        self.online_track_support = [None] * self.corr_levels
+        self.online_coords_predicted = None
+        self.online_vis_predicted = None
+        self.online_conf_predicted = None
+
+    @torch.no_grad()
+    def forward(self, video, queries, iters=4, is_train=False, add_space_attn=True, fmaps_chunk_size=200,
+                is_online=False):
+        B, T, H, W = self._check_inputs(video, queries, is_train)
+        S = self.window_len
+        assert S >= 2
+        if is_online:
+            assert T <= S, "Online mode: video chunk must be <= window size."
+            assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
+        if B != 1 and is_online:
+            raise NotImplementedError("online mode supports B=1")
+        outs = [self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, is_online) for b in range(B)]
+        coords = torch.stack([o[0] for o in outs])
+        vis = torch.stack([o[1] for o in outs])
+        conf = torch.stack([o[2] for o in outs])
+        return coords, vis, conf, None
+
+    def _forward_one(self, video, queries, iters, chunk, is_online):
+        T = video.shape[0]
+        N = queries.shape[0]
+        S = self.window_len
+        step = S // 2
+        dev = video.device
+        pw = self.packed(dev)
+        queries = queries.float()
+        qframes = queries[:, 0].long()                      # cotracker3_online.py:333
+        qcoords = (queries[:, 1:3] / self.stride).contiguous()  # :335-336
+
+        # encoder + pyramid.  The reference pads the *video* by repeating its last frame
+        # (:321-328); the encoder is per-frame, so repeating the last feature map is identical.
+        pad = (S - T) if is_online else (S - T % S) % S
+        f0 = self._encode(video.float(), chunk)
+        if pad > 0:
+            f0 = torch.cat([f0, f0[-1:].expand(pad, -1, -1, -1)], dim=0).contiguous()
+        pyr = ops.build_pyramid(f0, self.corr_levels)
+
+        coords_pred = torch.zeros(T, N, 2, device=dev)
+        vis_pred = torch.zeros(T, N, device=dev)
+        conf_pred = torch.zeros(T, N, device=dev)
+        if is_online:
+            if self.online_coords_predicted is not None:  # :349-360
+                p = min(step, T - step)
+                coords_pred = F.pad(self.online_coords_predicted, (0, 0, 0, 0, 0, p))
+                vis_pred = F.pad(self.online_vis_predicted, (0, 0, 0, p))
+                conf_pred = F.pad(self.online_conf_predicted, (0, 0, 0, p))
+            left = 0 if self.online_ind == 0 else self.online_ind + step
+            right = self.online_ind + S
+            sample_mask = ((qframes >= left) & (qframes < right)).float()[:, None, None]  # :411-414
+            frames_rel = (qframes - self.online_ind).float().contiguous()
+        else:
+            frames_rel = qframes.float().contiguous()
+
+        support = self._support(pyr, frames_rel, qcoords)
+        if is_online:  # :424-440 -- accumulate only the tracks whose query frame is in this chunk
+            for l in range(self.corr_levels):
+                if self.online_track_support[l] is None:
+                    self.online_track_support[l] = torch.zeros_like(support[l])
+                self.online_track_support[l] = self.online_track_support[l] + support[l] * sample_mask
+                support[l] = self.online_track_support[l]
+
+        coords_init = qcoords[None].expand(S, N, 2).contiguous()
+        vis_init = torch.zeros(S, N, device=dev)
+        conf_init = torch.zeros(S, N, device=dev)
+
+        num_windows = (T - S + step - 1) // step + 1
+        indices = [self.online_ind] if is_online else range(0, step * num_windows, step)
+        for ind in indices:
+            if ind > 0:  # carry-over from the previous window, :457-482
+                overlap = S - step
+                copy_over = (qframes < ind + overlap)[None, :]
+                cprev = coords_pred[ind:ind + overlap] / self.stride
+                cprev = torch.cat([cprev, cprev[-1:].expand(step, -1, -1)], dim=0)
+                vprev = vis_pred[ind:ind + overlap]
+                vprev = torch.cat([vprev, vprev[-1:].expand(step, -1)], dim=0)
+                fprev = conf_pred[ind:ind + overlap]
+                fprev = torch.cat([fprev, fprev[-1:].expand(step, -1)], dim=0)
+                coords_init = torch.where(copy_over[..., None], cprev, coords_init).contiguous()
+                vis_init = torch.where(copy_over, vprev, vis_init).contiguous()
+                conf_init = torch.where(copy_over, fprev, conf_init).contiguous()
+            mask = (qframes < ind + S).to(torch.uint8).contiguous()  # attention_mask :484, used as :493-496
+            fm = pyr if is_online else [p_[ind:ind + S] for p_ in pyr]
+            coords = coords_init.clone()
+            vis = vis_init.clone()
+            conf = conf_init.clone()
+            win = ops.Window(fm, support, coords, vis, conf, self._scale_xy(), iters=iters, point_mask=mask,
+                             max_corr_rows=self.max_corr_rows)
+            ops.forward_window(win, pw)
+            S_trim = T if is_online else min(T - ind, S)
+            coords_pred[ind:ind + S] = (coords * float(self.stride))[:S_trim]
+            vis_pred[ind:ind + S] = vis[:S_trim]
+            conf_pred[ind:ind + S] = conf[:S_trim]
+        if is_online:
+            self.online_ind += step
+            self.online_coords_predicted = coords_pred
+            self.online_vis_predicted = vis_pred
+            self.online_conf_predicted = conf_pred
+        return coords_pred, torch.sigmoid(vis_pred), torch.sigmoid(conf_pred)
+
+
+class CoTrackerThreeOffline(CoTrackerThreeBase):
+    """Single-window tracker over all T frames (cotracker3_offline.py:15-233)."""
+
+    @torch.no_grad()
+    def forward(self, video, queries, iters=4, is_train=False, add_space_attn=True, fmaps_chunk_size=200):
+        B, T, H, W = self._check_inputs(video, queries, is_train)
+        assert T >= 1
+        outs = [self._forward_one(video[b], queries[b], iters, fmaps_chunk_size) for b in range(B)]
+        return (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]),
+                torch.stack([o[2] for o in outs]), None)
+
+    def _forward_one(self, video, queries, iters, chunk):
+        T = video.shape[0]
+        N = queries.shape[0]
+        dev = video.device
+        pw = self.packed(dev)
+        queries = queries.float()
+        qframes = queries[:, 0].long()
+        qcoords = (queries[:, 1:3] / self.stride).contiguous()
+        pyr = ops.build_pyramid(self._encode(video.float(), chunk), self.corr_levels)
+        support = self._support(pyr, qframes.float().contiguous(), qcoords)
+        coords = qcoords[None].expand(T, N, 2).contiguous()
+        vis = torch.zeros(T, N, device=dev)
+        conf = torch.zeros(T, N, device=dev)
+        win = ops.Window(pyr, support, coords, vis, conf, self._scale_xy(), iters=iters, point_mask=None,
+                         max_corr_rows=self.max_corr_rows)
+        ops.forward_window(win, pw)
+        return coords * float(self.stride), torch.sigmoid(vis), torch.sigmoid(conf)

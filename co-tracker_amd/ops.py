@@ -1,0 +1,231 @@
+"""Torch-tensor front end of the C-ABI ops (device memory + stream plumbing only).
+
+Every function enqueues HIP kernels from libctk_hip.so on the current torch stream; nothing here
+computes on the CPU and nothing falls back to PyTorch ops.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("expected contiguous float32 CUDA(HIP) tensors")
+
+
+# ------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, act: int = L.ACT_NONE, resid=None, bias_rows=None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + bias_rows[m % period]) + resid."""
+    _chk_f32(a, w, bias, resid, bias_rows, out)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    g = L.GemmArgs()
+    g.A, g.lda, g.M = _ptr(a), K, M
+    g.W, g.ldw, g.N, g.K = _ptr(w), w.shape[1], N, K
+    g.C, g.ldc = _ptr(out), out.stride(0)
+    g.bias = _ptr(bias)
+    g.bias_rows = _ptr(bias_rows)
+    g.bias_period = bias_rows.shape[0] if bias_rows is not None else 0
+    g.resid, g.ldr = _ptr(resid), (resid.stride(0) if resid is not None else 0)
+    g.act = act
+    g.batch, g.a_bs, g.c_bs = 1, 0, 0
+    L.check(L.load().ctk_gemm(C.byref(g), _stream()), "ctk_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma=None, beta=None, eps: float = 1e-6) -> torch.Tensor:
+    _chk_f32(x, gamma, beta)
+    assert x.shape[-1] == L.HID
+    y = torch.empty_like(x)
+    L.check(L.load().ctk_layernorm(_ptr(x), _ptr(y), x.numel() // L.HID, _ptr(gamma), _ptr(beta), float(eps), _stream()),
+            "ctk_layernorm")
+    return y
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, splits: int = 1) -> torch.Tensor:
+    """q [B,N1,384], k/v [B,N2,384] (8 heads x 48, heads contiguous in the last dim) -> [B,N1,384]."""
+    _chk_f32(q, k, v)
+    B, N1, _ = q.shape
+    N2 = k.shape[1]
+    out = torch.empty_like(q)
+    a = L.AttnArgs()
+    a.q, a.q_ld, a.q_bs, a.q_is = _ptr(q), L.HID, N1, 1
+    a.k, a.v, a.kv_ld, a.kv_bs, a.kv_is = _ptr(k), _ptr(v), L.HID, N2, 1
+    a.out, a.o_ld, a.o_bs, a.o_is = _ptr(out), L.HID, N1, 1
+    a.nbatch, a.n1, a.n2 = B, N1, N2
+    a.splits = splits
+    part = None
+    if splits > 1:
+        part = torch.empty(splits * B * 8 * N1 * 50, device=q.device, dtype=torch.float32)
+    a.partial = _ptr(part)
+    L.check(L.load().ctk_attention(C.byref(a), _stream()), "ctk_attention")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# pyramid / samplers
+# ------------------------------------------------------------------------------------------
+def normalize_to_nhwc(fmaps_nchw: torch.Tensor) -> torch.Tensor:
+    """[F,128,H,W] -> channel-L2-normalised NHWC [F,H,W,128] (cotracker3_online.py:384-394)."""
+    _chk_f32(fmaps_nchw)
+    F_, Cc, H, W = fmaps_nchw.shape
+    assert Cc == 128
+    out = torch.empty(F_, H, W, Cc, device=fmaps_nchw.device, dtype=torch.float32)
+    L.check(L.load().ctk_normalize_to_nhwc(_ptr(fmaps_nchw), F_, H, W, _ptr(out), _stream()), "ctk_normalize_to_nhwc")
+    return out
+
+
+def avg_pool2_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _chk_f32(x)
+    F_, H, W, Cc = x.shape
+    out = torch.empty(F_, H // 2, W // 2, Cc, device=x.device, dtype=torch.float32)
+    L.check(L.load().ctk_avg_pool2_nhwc(_ptr(x), F_, H, W, _ptr(out), _stream()), "ctk_avg_pool2_nhwc")
+    return out
+
+
+def build_pyramid(level0_nhwc: torch.Tensor, levels: int = L.LEVELS) -> List[torch.Tensor]:
+    pyr = [level0_nhwc]
+    for _ in range(levels - 1):
+        pyr.append(avg_pool2_nhwc(pyr[-1]))
+    return pyr
+
+
+def sample_support(fmap_nhwc: torch.Tensor, frames: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """get_track_feat (cotracker3_online.py:113-128): fmap [T,H,W,128], frames [N] float, coords [N,2] -> [N,49,128]."""
+    _chk_f32(fmap_nhwc, frames, coords)
+    T, H, W, _ = fmap_nhwc.shape
+    N = coords.shape[0]
+    out = torch.empty(N, 49, 128, device=coords.device, dtype=torch.float32)
+    L.check(L.load().ctk_sample_support(_ptr(fmap_nhwc), T, H, W, _ptr(frames), _ptr(coords), N, _ptr(out), _stream()),
+            "ctk_sample_support")
+    return out
+
+
+def sample_patches(fmap_nhwc: torch.Tensor, coords: torch.Tensor, level: int) -> torch.Tensor:
+    """get_correlation_feat (cotracker3_online.py:130-143): fmap [S,H,W,128], coords [S,N,2] level-0 -> [S,N,49,128]."""
+    _chk_f32(fmap_nhwc, coords)
+    S, H, W, _ = fmap_nhwc.shape
+    N = coords.shape[1]
+    out = torch.empty(S, N, 49, 128, device=coords.device, dtype=torch.float32)
+    L.check(L.load().ctk_sample_patches(_ptr(fmap_nhwc), S, H, W, _ptr(coords), N, level, _ptr(out), _stream()),
+            "ctk_sample_patches")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# window-level ops
+# ------------------------------------------------------------------------------------------
+class Window:
+    """Holds the ctypes ctk_window_args plus the tensors it points to."""
+
+    def __init__(self, fmaps: Sequence[torch.Tensor], support: Sequence[torch.Tensor], coords: torch.Tensor,
+                 vis: torch.Tensor, conf: torch.Tensor, scale_xy, iters: int = 6,
+                 point_mask: Optional[torch.Tensor] = None, max_corr_rows: int = 262144):
+        _chk_f32(*fmaps, *support, coords, vis, conf)
+        S, N = coords.shape[0], coords.shape[1]
+        assert coords.shape == (S, N, 2) and vis.shape == (S, N) and conf.shape == (S, N)
+        a = L.WindowArgs()
+        a.S, a.N, a.iters = S, N, iters
+        for l in range(L.LEVELS):
+            assert fmaps[l].shape[0] == S and fmaps[l].shape[3] == 128
+            assert support[l].shape == (N, 49, 128)
+            a.H[l], a.W[l] = fmaps[l].shape[1], fmaps[l].shape[2]
+            a.fmaps[l] = _ptr(fmaps[l])
+            a.support[l] = _ptr(support[l])
+        if point_mask is not None:
+            assert point_mask.dtype == torch.uint8 and point_mask.is_cuda and point_mask.shape == (N,)
+        a.point_mask = _ptr(point_mask)
+        a.coords, a.vis, a.conf = _ptr(coords), _ptr(vis), _ptr(conf)
+        a.scale_x, a.scale_y = float(scale_xy[0]), float(scale_xy[1])
+        a.points_per_chunk = max(1, min(N, max_corr_rows // S))
+        self.args = a
+        self.S, self.N = S, N
+        self.keep = (list(fmaps), list(support), coords, vis, conf, point_mask)
+        self.device = coords.device
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _ws_cache.pop(key, None)
+        buf = None
+        buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        _ws_cache[key] = buf
+    return buf
+
+
+def forward_window(win: Window, weights) -> None:
+    """`iters` update iterations in place on win's coords/vis/conf (cotracker3_online.py:171-264)."""
+    lib = L.load()
+    nbytes = C.c_size_t(0)
+    L.check(lib.ctk_forward_window_workspace_bytes(C.byref(win.args), C.byref(nbytes)), "ctk_forward_window_workspace_bytes")
+    ws = _workspace(nbytes.value, win.device)
+    mw = weights.struct_for(win.S)
+    L.check(lib.ctk_forward_window(C.byref(win.args), C.byref(mw), _ptr(ws), ws.numel(), _stream()), "ctk_forward_window")
+
+
+def corr_volume(win: Window) -> torch.Tensor:
+    out = torch.empty(L.LEVELS, win.N * win.S, L.CORR_LD, device=win.device, dtype=torch.float32)
+    L.check(L.load().ctk_corr_volume(C.byref(win.args), _ptr(out), _stream()), "ctk_corr_volume")
+    return out
+
+
+def corr_embed(win: Window, weights, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    if x is None:
+        x = torch.zeros(win.N * win.S, L.X_LD, device=win.device, dtype=torch.float32)
+    nbytes = C.c_size_t(0)
+    L.check(lib.ctk_corr_embed_workspace_bytes(C.byref(win.args), C.byref(nbytes)), "ctk_corr_embed_workspace_bytes")
+    ws = _workspace(nbytes.value, win.device)
+    mw = weights.struct_for(win.S)
+    L.check(lib.ctk_corr_embed(C.byref(win.args), C.byref(mw), _ptr(x), _ptr(ws), ws.numel(), _stream()), "ctk_corr_embed")
+    return x
+
+
+def assemble_tokens(win: Window, x: torch.Tensor) -> torch.Tensor:
+    L.check(L.load().ctk_assemble_tokens(C.byref(win.args), _ptr(x), _stream()), "ctk_assemble_tokens")
+    return x
+
+
+def tap_indices(win: Window) -> torch.Tensor:
+    out = torch.empty(win.S, win.N, L.LEVELS, 2, 7, device=win.device, dtype=torch.int32)
+    L.check(L.load().ctk_tap_indices(C.byref(win.args), _ptr(out), _stream()), "ctk_tap_indices")
+    return out
+
+
+def update_former(x: torch.Tensor, S: int, N: int, weights) -> torch.Tensor:
+    """x [N*S, 1120] (our column layout) -> delta [N*S,4]."""
+    _chk_f32(x)
+    lib = L.load()
+    nbytes = C.c_size_t(0)
+    L.check(lib.ctk_update_former_workspace_bytes(S, N, C.byref(nbytes)), "ctk_update_former_workspace_bytes")
+    ws = _workspace(nbytes.value, x.device)
+    delta = torch.empty(N * S, 4, device=x.device, dtype=torch.float32)
+    mw = weights.struct_for(S)
+    L.check(lib.ctk_update_former(S, N, _ptr(x), C.byref(mw), _ptr(delta), _ptr(ws), ws.numel(), _stream()), "ctk_update_former")
+    return delta

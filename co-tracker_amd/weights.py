@@ -54,4 +54,7 @@ def fill_synthetic_(module: torch.nn.Module, seed: int = 0, head_scale: float = 
         if name == "time_emb":  # deterministic buffer (embeddings.py:59-84), keep
             continue
         t.copy_(synthetic_tensor(name, t.shape, seed, head_scale).to(t.device, t.dtype))
+    inval = getattr(module, "invalidate_packed_weights", None)
+    if inval is not None:  # cotracker_amd models cache device-side repacked weights
+        inval()
     return module

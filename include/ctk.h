@@ -1,0 +1,199 @@
+/*
+ * ctk.h -- C-ABI of the MI355X (gfx950) CoTracker3 iterative-update hot path.
+ *
+ * The reference (facebookresearch/co-tracker @ 2025-03-04) is pure Python/PyTorch and
+ * has no FFI; each entry point below replaces the reference interface cited beside
+ * it (paths relative to the reference root), at the operator boundary fixed in
+ * SURVEY.md section 8(b).  INTEGRATION.md shows the ctypes binding a maintainer
+ * would add to cotracker/models/core/cotracker/cotracker3_online.py.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory (float32 unless
+ *    stated) owned by the caller; the library never allocates, frees or retains
+ *    device memory and keeps no mutable global state (re-entrant).
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no host
+ *    synchronisation, no host reads of device data -> safe under stream capture.
+ *  - return value: 0 ok, <0 invalid argument (CTK_E_*), >0 a hipError_t.
+ *  - batch size B = 1 per call (every reference config has B = 1; the Python host
+ *    loops over B).  C = 128 feature channels, hidden = 384, heads = 8 x 48,
+ *    mlp = 1536, 64 virtual tracks, 4 pyramid levels, 7x7 taps -- the values fixed by
+ *    cotracker/models/build_cotracker.py:31-38 and cotracker3_online.py:43-84.
+ *
+ * Data layout (ours, not the reference's)
+ *  - feature pyramid level l: NHWC  [T, H_l, W_l, 128]   (reference: [B,T,128,H,W])
+ *  - support patches   level l: [N, 49, 128]             (reference: [B,49,N,128])
+ *  - window state: coords [S,N,2] (level-0 feature units), vis [S,N], conf [S,N] logits
+ *  - transformer input x: [N*S, CTK_X_LD] row = n*S+t, columns
+ *        [0,1024) corr embeddings (level-major), 1024 vis, 1025 conf,
+ *        [1026,1110) posenc(84), [1110,1120) zero padding
+ *    (reference order is [vis,conf,corr,posenc], cotracker3_online.py:212-245; the
+ *    host permutes input_transform.weight columns once at load time)
+ *  - tokens: [(N+64)*S, 384], row = n*S+t, virtual tracks are n = N..N+63
+ */
+#ifndef CTK_H_
+#define CTK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTK_ABI_VERSION 1
+#define CTK_LEVELS 4
+#define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
+#define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
+#define CTK_CORR_K 2401    /* 49*49                            cotracker3_online.py:84  */
+#define CTK_CORR_LD 2432   /* 2401 padded to a multiple of 32 (zero columns)            */
+#define CTK_HID 384        /* hidden_size                      cotracker3_online.py:77  */
+#define CTK_HEADS 8
+#define CTK_HEAD_DIM 48
+#define CTK_MLP 1536
+#define CTK_VIRT 64        /* num_virtual_tracks               cotracker3_online.py:49  */
+#define CTK_X_DIM 1110     /* input_dim                        cotracker3_online.py:71  */
+#define CTK_X_LD 1120      /* 1110 padded to a multiple of 32                           */
+#define CTK_X_CORR 0
+#define CTK_X_VIS 1024
+#define CTK_X_CONF 1025
+#define CTK_X_POSENC 1026
+#define CTK_DEPTH 3        /* time_depth = space_depth = 3     cotracker3_online.py:74-75 */
+
+enum {
+  CTK_OK = 0,
+  CTK_E_NULL = -1,      /* required pointer is NULL            */
+  CTK_E_SHAPE = -2,     /* size out of range / not supported   */
+  CTK_E_ALIGN = -3,     /* pointer or leading dimension not 16-byte aligned */
+  CTK_E_WORKSPACE = -4  /* workspace too small                 */
+};
+
+enum { CTK_ACT_NONE = 0, CTK_ACT_GELU_ERF = 1, CTK_ACT_GELU_TANH = 2 };
+
+/* Weights of one transformer block (AttnBlock blocks.py:401-438 or CrossAttnBlock
+ * cotracker.py:534-577).  Linear weights are torch layout [out,in] row-major.        */
+typedef struct ctk_block_weights {
+  const float* wq;   const float* bq;    /* to_q      [384,384],[384]   blocks.py:375 */
+  const float* wkv;  const float* bkv;   /* to_kv     [768,384],[768]   blocks.py:376 (k rows 0..383, v rows 384..767) */
+  const float* wo;   const float* bo;    /* to_out    [384,384],[384]   blocks.py:377 */
+  const float* w1;   const float* b1;    /* mlp.fc1   [1536,384],[1536] blocks.py:61  */
+  const float* w2;   const float* b2;    /* mlp.fc2   [384,1536],[384]  blocks.py:67  */
+  const float* ctx_gamma; const float* ctx_beta; /* norm_context [384] (cotracker.py:540) or NULL for AttnBlock */
+} ctk_block_weights;
+
+/* EfficientUpdateFormer (cotracker.py:387-531) + corr_mlp (cotracker3_online.py:84). */
+typedef struct ctk_model_weights {
+  const float* corr_fc1_w;   /* [384, CTK_CORR_LD] zero-padded columns */
+  const float* corr_fc1_b;   /* [384]  */
+  const float* corr_fc2_w;   /* [256,384] */
+  const float* corr_fc2_b;   /* [256]  */
+  const float* in_w;         /* input_transform.weight, columns permuted to the x layout, [384, CTK_X_LD] */
+  const float* in_bias_t;    /* [S,384] = input_transform.bias + W @ time_emb_S[t]  (time embedding
+                                 folded into the projection: W(x+e_t)+b = Wx + (W e_t + b),
+                                 cotracker3_online.py:247 + cotracker.py:484) */
+  const float* virtual_tokens; /* virual_tracks [64,384]        cotracker.py:416 */
+  const float* head_w;       /* [4,384] = cat(flow_head.weight, vis_conf_head.weight)  cotracker.py:526-529 */
+  const float* head_b;       /* [4] */
+  ctk_block_weights time_blocks[CTK_DEPTH];
+  ctk_block_weights virtual2point[CTK_DEPTH];
+  ctk_block_weights virtual_self[CTK_DEPTH];
+  ctk_block_weights point2virtual[CTK_DEPTH];
+} ctk_model_weights;
+
+/* One sliding window / offline pass.  Replaces CoTrackerThreeOnline.forward_window
+ * (cotracker3_online.py:171-264) and the inline loop of cotracker3_offline.py:139-216. */
+typedef struct ctk_window_args {
+  int32_t S;                  /* frames in the window (16 online/sliding, T offline)  */
+  int32_t N;                  /* tracked points                                       */
+  int32_t iters;              /* update iterations (predictor.py:158 uses 6)          */
+  int32_t H[CTK_LEVELS];      /* level sizes                                          */
+  int32_t W[CTK_LEVELS];
+  const float* fmaps[CTK_LEVELS];   /* NHWC [S,H_l,W_l,128], first frame of the window */
+  const float* support[CTK_LEVELS]; /* [N,49,128]                                      */
+  const uint8_t* point_mask;  /* [N] 1 = track already queried (attention_mask, cotracker3_online.py:484,493-496); NULL = all 1 */
+  float* coords;              /* [S,N,2] in/out, level-0 feature units                 */
+  float* vis;                 /* [S,N]   in/out, logits                                */
+  float* conf;                /* [S,N]   in/out, logits                                */
+  float scale_x, scale_y;     /* model_resolution / stride = (W/4, H/4)  cotracker3_online.py:224-232 */
+  int32_t points_per_chunk;   /* correlation stage processes this many points at a time (0 = all) */
+} ctk_window_args;
+
+int ctk_abi_version(void);
+const char* ctk_error_string(int code);
+
+/* ---- whole-window driver (Op A + C + B + state update, `iters` times) ----------- */
+int ctk_forward_window_workspace_bytes(const ctk_window_args* a, size_t* out_bytes);
+int ctk_forward_window(const ctk_window_args* a, const ctk_model_weights* w,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Op A: corr_embed  (cotracker3_online.py:190-210; get_correlation_feat :130-143,
+ *      einsum :202-204, corr_mlp :205) -> x[:, 0:1024]                                */
+int ctk_corr_embed_workspace_bytes(const ctk_window_args* a, size_t* out_bytes);
+int ctk_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* x /*[N*S,CTK_X_LD]*/,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* 49x49 correlation volume only (before corr_mlp), for parity tests:
+ * out [4][N*S][CTK_CORR_LD], row = n*S+t.                                             */
+int ctk_corr_volume(const ctk_window_args* a, float* out, void* stream);
+
+/* ---- Op C: assemble_tokens (cotracker3_online.py:212-245, posenc :19-39) -> x[:,1024:1120] */
+int ctk_assemble_tokens(const ctk_window_args* a, float* x, void* stream);
+
+/* ---- Op B: EfficientUpdateFormer.forward (cotracker.py:483-531): x -> delta [N*S,4] */
+int ctk_update_former_workspace_bytes(int32_t S, int32_t N, size_t* out_bytes);
+int ctk_update_former(int32_t S, int32_t N, const float* x, const ctk_model_weights* w,
+                      float* delta /*[N*S,4] row=n*S+t*/, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Op D: standalone samplers --------------------------------------------------- */
+/* Integer floor indices (x0,y0) of the 7 x-taps and 7 y-taps of every (t,n,level), exactly as
+ * bilinear_sampler + ATen grid_sampler_3d compute them (model_utils.py:238-255).
+ * out int32 [S,N,4,2,7].  The bit-exactness contract of BASELINE.md section 2.          */
+int ctk_tap_indices(const ctk_window_args* a, int32_t* out, void* stream);
+/* get_correlation_feat (cotracker3_online.py:130-143) for one level: out [S,N,49,128].  */
+int ctk_sample_patches(const float* fmap /*NHWC [S,H,W,128]*/, int32_t S, int32_t H, int32_t W,
+                       const float* coords /*[S,N,2] level-0 units*/, int32_t N, int32_t level,
+                       float* out, void* stream);
+/* get_track_feat (cotracker3_online.py:113-128, sample_features5d model_utils.py:293-323):
+ * trilinear support patches for one level.  fmap NHWC [T,H,W,128]; frames [N] float (frame
+ * index relative to fmap[0]); coords [N,2] in this level's units; out [N,49,128].        */
+int ctk_sample_support(const float* fmap, int32_t T, int32_t H, int32_t W, const float* frames,
+                       const float* coords, int32_t N, float* out, void* stream);
+/* Channel L2-normalise + NCHW->NHWC (cotracker3_online.py:384-394) and 2x2 average pooling
+ * (:401-409).  in [F,128,H,W] -> out NHWC [F,H,W,128]; pool: in NHWC [F,H,W,128] -> [F,H/2,W/2,128]. */
+int ctk_normalize_to_nhwc(const float* in, int32_t F, int32_t H, int32_t W, float* out, void* stream);
+int ctk_avg_pool2_nhwc(const float* in, int32_t F, int32_t H, int32_t W, float* out, void* stream);
+
+/* ---- primitives (exported for unit tests and reuse) ------------------------------ */
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N] + bias_rows[(m % period),N]) + resid[M,N]
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32).  N % 64 == 0, K % 32 == 0, lda/ldw % 4 == 0,
+ * A and W 16-byte aligned.  batch > 1 repeats with element strides a_bs / c_bs (shared W). */
+typedef struct ctk_gemm_args {
+  const float* A; int64_t lda; int32_t M;
+  const float* W; int64_t ldw; int32_t N; int32_t K;
+  float* C; int64_t ldc;
+  const float* bias;
+  const float* bias_rows; int32_t bias_period;
+  const float* resid; int64_t ldr;
+  int32_t act;
+  int32_t batch; int64_t a_bs; int64_t c_bs;
+} ctk_gemm_args;
+int ctk_gemm(const ctk_gemm_args* g, void* stream);
+
+/* LayerNorm over 384 channels, rows [0,R): y = (x-mean)/sqrt(var+eps) [*gamma+beta].  */
+int ctk_layernorm(const float* x, float* y, int64_t R, const float* gamma, const float* beta,
+                  float eps, void* stream);
+
+/* softmax(q k^T * 48^-0.5) v  (Attention.forward, blocks.py:379-398), 8 heads x 48.
+ * row(b,i) = b*bs + i*is (rows of a matrix with leading dimension ld floats).           */
+typedef struct ctk_attn_args {
+  const float* q; int64_t q_ld; int64_t q_bs; int64_t q_is;
+  const float* k; const float* v; int64_t kv_ld; int64_t kv_bs; int64_t kv_is;
+  float* out; int64_t o_ld; int64_t o_bs; int64_t o_is;
+  int32_t nbatch; int32_t n1; int32_t n2;
+  int32_t splits;          /* key-range splits (>1 needs workspace) */
+  float* partial;          /* [splits, nbatch, 8, n1, 50] or NULL    */
+} ctk_attn_args;
+int ctk_attention(const ctk_attn_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTK_H_ */

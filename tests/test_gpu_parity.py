@@ -1,0 +1,436 @@
+"""GPU parity tests: the HIP path (through the C-ABI, libctk_hip.so) against
+ (a) golden vectors produced by the unmodified reference (tests/golden/*.npz),
+ (b) the numpy oracle on seeded inputs, and (c) torch fp64 for the GEMM/attention primitives.
+
+Tolerances are BASELINE.md's: coords <= 1e-3 px, visibility/confidence logits <= 1e-4, sampler
+floor indices and sampled values bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cotracker_oracle as O  # noqa: E402  (checker only)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def maxdiff(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max())
+
+
+def logit(p):
+    p = p.detach().cpu().double() if torch.is_tensor(p) else torch.from_numpy(np.asarray(p)).double()
+    return torch.log(p / (1 - p))
+
+
+def to_nhwc(f):  # [S,C,H,W] numpy -> NHWC device tensor
+    return t(np.transpose(f, (0, 2, 3, 1)))
+
+
+def x_to_ours(x_ref):
+    """[N,S,1110] reference column order -> [N*S,1120] ours."""
+    from cotracker_amd import _lib as L
+    N, S, _ = x_ref.shape
+    x = torch.zeros(N * S, L.X_LD, device=x_ref.device)
+    xr = x_ref.reshape(N * S, -1)
+    x[:, 0:1024] = xr[:, 2:1026]
+    x[:, 1024:1026] = xr[:, 0:2]
+    x[:, 1026:1110] = xr[:, 1026:1110]
+    return x
+
+
+@pytest.fixture(scope="module")
+def ops_model():
+    """Online model with the synthetic weights the ops.npz goldens were made with."""
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(96, 128)).eval()
+    fill_synthetic_(m, seed=3)
+    return m.to(dev())
+
+
+def make_window(g, model, coords=None, vis=None, conf=None, iters=1, mask=None):
+    from cotracker_amd import ops
+    fm = [to_nhwc(g[f"fmaps{i}"][0]) for i in range(4)]
+    sup = [t(np.transpose(g[f"support{i}"][0], (1, 0, 2))) for i in range(4)]  # [49,N,C] -> [N,49,C]
+    coords = t(g["coords"][0]) if coords is None else coords
+    S, N = coords.shape[:2]
+    vis = torch.zeros(S, N, device=dev()) if vis is None else vis
+    conf = torch.zeros(S, N, device=dev()) if conf is None else conf
+    return ops.Window(fm, sup, coords, vis, conf, (128 / 4, 96 / 4), iters=iters, point_mask=mask)
+
+
+# ------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(1000, 384, 1152), (257, 2432, 384), (64, 1536, 384), (16500, 1120, 384),
+                                   (20000, 384, 1536)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm(M, K, N, act):
+    from cotracker_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + K + N + act)
+    a = torch.randn(M, K, generator=g).to(dev())
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev())
+    bias = torch.randn(N, generator=g).to(dev())
+    resid = torch.randn(M, N, generator=g).to(dev())
+    brows = torch.randn(8, N, generator=g).to(dev())
+    out = ops.gemm(a, w, bias=bias, act=act, resid=resid, bias_rows=brows)
+    ref = a.double() @ w.double().t() + bias.double() + brows.double()[torch.arange(M, device=dev()) % 8]
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    ref = ref + resid.double()
+    assert maxdiff(out, ref) < 2e-5
+    # transposition-detecting: plain product with asymmetric operands and no epilogue
+    out2 = ops.gemm(a, w)
+    assert maxdiff(out2, a.double() @ w.double().t()) < 2e-5
+
+
+def test_gemm_inplace_residual_and_strided_out():
+    from cotracker_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(300, 384, generator=g).to(dev())
+    w = (torch.randn(256, 384, generator=g) / 20).to(dev())
+    big = torch.zeros(300, 1120, device=dev())
+    ops.gemm(a, w, out=big[:, 256:512])
+    assert maxdiff(big[:, 256:512], a.double() @ w.double().t()) < 2e-5
+    assert float(big[:, :256].abs().max()) == 0 and float(big[:, 512:].abs().max()) == 0
+    tok = torch.randn(300, 256, generator=g).to(dev())
+    ref = tok.double() + a.double() @ w.double().t()
+    ops.gemm(a, w, resid=tok, out=tok)
+    assert maxdiff(tok, ref) < 2e-5
+
+
+@pytest.mark.parametrize("affine", [False, True])
+def test_layernorm(affine):
+    from cotracker_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(1237, 384, generator=g) * 3 + 0.5).to(dev())
+    gamma = torch.randn(384, generator=g).to(dev()) if affine else None
+    beta = torch.randn(384, generator=g).to(dev()) if affine else None
+    eps = 1e-5 if affine else 1e-6
+    y = ops.layernorm(x, gamma, beta, eps)
+    ref = torch.nn.functional.layer_norm(x.double(), (384,), gamma.double() if affine else None,
+                                         beta.double() if affine else None, eps)
+    assert maxdiff(y, ref) < 5e-6
+
+
+@pytest.mark.parametrize("B,N1,N2,splits", [(37, 16, 16, 1), (5, 120, 120, 1), (16, 64, 700, 4), (3, 200, 64, 1),
+                                            (7, 48, 48, 1), (9, 8, 8, 1), (2, 64, 64, 1), (4, 64, 1500, 32)])
+def test_attention(B, N1, N2, splits):
+    from cotracker_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N1 + N2)
+    q = torch.randn(B, N1, 384, generator=g).to(dev())
+    k = torch.randn(B, N2, 384, generator=g).to(dev())
+    v = torch.randn(B, N2, 384, generator=g).to(dev())
+    out = ops.attention(q, k, v, splits=splits)
+    qh = q.double().reshape(B, N1, 8, 48).transpose(1, 2)
+    kh = k.double().reshape(B, N2, 8, 48).transpose(1, 2)
+    vh = v.double().reshape(B, N2, 8, 48).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 48 ** -0.5, -1) @ vh).transpose(1, 2).reshape(B, N1, 384)
+    assert maxdiff(out, ref) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------
+# samplers (bit-exact)
+# ------------------------------------------------------------------------------------------
+def _tap_idx(c, sizes):
+    from cotracker_amd import _lib as L
+    import ctypes as C
+    S, N = c.shape[:2]
+    a = L.WindowArgs()
+    a.S, a.N, a.iters = S, N, 0
+    ct = t(c)
+    for l, (H, W) in enumerate(sizes):
+        a.H[l], a.W[l] = H, W
+    a.coords = ct.data_ptr()
+    out = torch.empty(S, N, 4, 2, 7, dtype=torch.int32, device=dev())
+    L.check(L.load().ctk_tap_indices(C.byref(a), out.data_ptr(), torch.cuda.current_stream().cuda_stream), "tap")
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("sizes", [[(24, 32), (12, 16), (6, 8), (3, 4)], [(96, 128), (48, 64), (24, 32), (12, 16)]])
+def test_tap_indices_bit_exact(sizes):
+    """Floor indices of every tap, bit-exact vs the ATen restatement; integer / half-integer /
+    out-of-range coordinates included (the normalise->unnormalise round trip is not the identity)."""
+    H0, W0 = sizes[0]
+    r = np.random.RandomState(0)
+    S, N = 6, 3000
+    c = np.empty((S, N, 2), np.float32)
+    c[..., 0] = r.uniform(-6, W0 + 6, size=(S, N))
+    c[..., 1] = r.uniform(-6, H0 + 6, size=(S, N))
+    c[:, :1000] = np.round(c[:, :1000])
+    c[:, 1000:1400] = np.round(c[:, 1000:1400] * 2) / 2
+    c[0, :, 0] = np.arange(N) % W0
+    c[0, :, 1] = np.arange(N) % H0
+    idx = _tap_idx(c, sizes)
+    for l, (H, W) in enumerate(sizes):
+        x0, y0 = O.sampler_floor_indices((c / np.float32(2 ** l)).astype(np.float32), H, W)
+        assert np.array_equal(idx[:, :, l, 0], x0)
+        assert np.array_equal(idx[:, :, l, 1], y0)
+
+
+def test_sample_patches_bit_exact(golden):
+    from cotracker_amd import ops
+    g = golden("ops")
+    B, S, N, _ = g["coords"].shape
+    for l in range(4):
+        out = ops.sample_patches(to_nhwc(g[f"fmaps{l}"][0]), t(g["coords"][0]), l).cpu().numpy()
+        ref = O.get_correlation_feat(g[f"fmaps{l}"], (g["coords"].reshape(B * S, N, 2) / np.float32(2 ** l)))
+        assert np.array_equal(out, ref[0].reshape(S, N, 49, 128))
+
+
+def test_sample_support_bit_exact(golden):
+    from cotracker_amd import ops
+    g = golden("ops")
+    for l in range(4):
+        out = ops.sample_support(to_nhwc(g[f"fmaps{l}"][0]), t(g["queried_frames"][0].astype(np.float32)),
+                                 t((g["queried_coords"][0] / np.float32(2 ** l)).astype(np.float32))).cpu().numpy()
+        ref = np.transpose(g[f"support{l}"][0], (1, 0, 2))
+        assert np.array_equal(out, ref)
+
+
+def test_normalize_and_pool():
+    from cotracker_amd import ops
+    r = np.random.RandomState(5)
+    f = r.standard_normal((3, 128, 24, 32)).astype(np.float32)
+    out = ops.normalize_to_nhwc(t(f))
+    ref = np.transpose(O.normalize_fmaps(f[None])[0], (0, 2, 3, 1))
+    assert maxdiff(out, ref) < 2e-7
+    pooled = ops.avg_pool2_nhwc(out).cpu().numpy()
+    refp = np.transpose(O.avg_pool2(np.transpose(out.cpu().numpy(), (0, 3, 1, 2))), (0, 2, 3, 1))
+    assert np.array_equal(pooled, refp)
+
+
+# ------------------------------------------------------------------------------------------
+# correlation path
+# ------------------------------------------------------------------------------------------
+def test_corr_volume(golden, ops_model):
+    from cotracker_amd import ops
+    g = golden("ops")
+    win = make_window(g, ops_model)
+    S, N = win.S, win.N
+    vol = ops.corr_volume(win)  # [4, N*S, 2432], row = n*S+t
+    assert float(vol[:, :, 2401:].abs().max()) == 0.0
+    for l in (0, 3):
+        ours = vol[l, :, :2401].reshape(N, S, 2401).transpose(0, 1).cpu().numpy()
+        assert maxdiff(ours, g[f"corr_volume{l}"][0]) < 2e-6
+    # masked (not yet queried) tracks give an all-zero volume (cotracker3_online.py:493-496)
+    mask = torch.ones(N, dtype=torch.uint8, device=dev())
+    mask[::3] = 0
+    win2 = make_window(g, ops_model, mask=mask)
+    vol2 = ops.corr_volume(win2).reshape(4, N, S, -1)
+    assert float(vol2[:, ::3].abs().max()) == 0.0
+    assert maxdiff(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3]) == 0.0
+
+
+def test_corr_embed(golden, ops_model):
+    from cotracker_amd import ops
+    g = golden("ops")
+    win = make_window(g, ops_model)
+    S, N = win.S, win.N
+    x = ops.corr_embed(win, ops_model.packed(dev()))
+    for l in range(4):
+        ours = x[:, l * 256:(l + 1) * 256].reshape(N, S, 256).transpose(0, 1)
+        assert maxdiff(ours, g[f"corr_emb{l}"][0]) < 1e-5
+    # chunked over points gives identical results
+    win.args.points_per_chunk = 5
+    x2 = ops.corr_embed(win, ops_model.packed(dev()))
+    assert maxdiff(x, x2) == 0.0
+
+
+def test_assemble_tokens(golden, ops_model):
+    from cotracker_amd import ops, _lib as L
+    g = golden("ops")
+    r = np.random.RandomState(2)
+    S, N = 8, 12
+    coords = (g["coords"][0] + r.uniform(-1, 1, size=(S, N, 2))).astype(np.float32)
+    vis = r.standard_normal((S, N)).astype(np.float32)
+    conf = r.standard_normal((S, N)).astype(np.float32)
+    win = make_window(g, ops_model, coords=t(coords), vis=t(vis), conf=t(conf))
+    x = torch.full((N * S, L.X_LD), 7.0, device=dev())
+    ops.assemble_tokens(win, x)
+    ref = O.assemble_tokens(coords[None], vis[None, ..., None], conf[None, ..., None],
+                            np.zeros((1, S, N, 1024), np.float32), np.zeros((1, 8, 1110), np.float32),
+                            model_resolution=(96, 128))[0]  # [N,S,1110]
+    ours = x.reshape(N, S, -1).cpu().numpy()
+    assert np.array_equal(ours[..., 1024], ref[..., 0]) and np.array_equal(ours[..., 1025], ref[..., 1])
+    assert maxdiff(ours[..., 1026:1110], ref[..., 1026:1110]) < 1e-6
+    assert float(np.abs(ours[..., 1110:]).max()) == 0.0
+    assert float(np.abs(ours[..., :1024] - 7.0).max()) == 0.0  # correlation columns untouched
+
+
+def test_update_former(golden, ops_model):
+    from cotracker_amd import ops
+    g = golden("ops")
+    pw = ops_model.packed(dev())
+    x_ref = t(g["uf_x"][0])  # [N,S,1110] = already includes whatever the caller added
+    N, S, _ = x_ref.shape
+    # ctk_update_former folds the time embedding into the projection bias: feed x - e_t
+    x = x_to_ours(x_ref - pw.time_embed(S)[None])
+    delta = ops.update_former(x, S, N, pw).reshape(N, S, 4)
+    assert maxdiff(delta, g["uf_delta"][0]) < 3e-5
+
+
+def test_forward_window(golden, ops_model):
+    from cotracker_amd import ops
+    g = golden("ops")
+    pw = ops_model.packed(dev())
+    S, N = 8, 12
+    qc = t(g["queried_coords"][0])
+    for iters in (1, 2, 3):
+        coords = qc[None].expand(S, N, 2).contiguous()
+        vis = t(g["fw_vis_init"][0, ..., 0])
+        conf = t(g["fw_conf_init"][0, ..., 0])
+        win = make_window(g, ops_model, coords=coords, vis=vis, conf=conf, iters=iters)
+        ops.forward_window(win, pw)
+        it = iters - 1
+        assert maxdiff(coords * 4.0, g[f"fw_coords{it}"][0]) < 1e-3
+        assert maxdiff(vis, g[f"fw_vis{it}"][0]) < 1e-4
+        assert maxdiff(conf, g[f"fw_conf{it}"][0]) < 1e-4
+
+
+def test_forward_window_vs_oracle_random():
+    """Seeded random window (S=16, N=37, real 4-level pyramid 48x64) against the numpy oracle."""
+    from cotracker_amd import ops
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=16, model_resolution=(192, 256)).eval()
+    fill_synthetic_(m, seed=11)
+    p = {k: v.numpy() for k, v in m.state_dict().items() if not k.startswith("fnet.")}
+    m = m.to(dev())
+    r = np.random.RandomState(4)
+    S, N = 16, 37
+    f = r.standard_normal((1, S, 128, 48, 64)).astype(np.float32)
+    pyr = O.build_pyramid(O.normalize_fmaps(f))
+    qf = r.randint(0, S, size=(1, N))
+    qc = (r.uniform(0, 1, size=(1, N, 2)) * np.array([63, 47])).astype(np.float32)
+    sup = [O.get_track_feat(pyr[i], qf, (qc / np.float32(2 ** i)).astype(np.float32)) for i in range(4)]
+    cinit = np.broadcast_to(qc.reshape(1, 1, N, 2), (1, S, N, 2)).astype(np.float32)
+    c, v, cf = O.forward_window(pyr, cinit, sup, np.zeros((1, S, N, 1), np.float32), np.zeros((1, S, N, 1), np.float32),
+                                p, iters=2, model_resolution=(192, 256))
+    fm = [to_nhwc(x[0]) for x in pyr]
+    sp = [t(np.transpose(s[0], (1, 0, 2))) for s in sup]
+    coords, vis, conf = t(cinit[0]), torch.zeros(S, N, device=dev()), torch.zeros(S, N, device=dev())
+    win = ops.Window(fm, sp, coords, vis, conf, (64.0, 48.0), iters=2)
+    ops.forward_window(win, m.packed(dev()))
+    assert maxdiff(coords, c[0]) < 2.5e-4  # feature units (x4 = px)
+    assert maxdiff(vis, v[0, ..., 0]) < 1e-4
+    assert maxdiff(conf, cf[0, ..., 0]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------
+# models and predictors (encoder on PyTorch-ROCm + HIP hot path) vs reference goldens
+# ------------------------------------------------------------------------------------------
+def test_model_online_sliding_and_streaming(golden):
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_online")
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=1)
+    m = m.to(dev())
+    video, q = t(g["on_video"]), t(g["on_queries"])
+    c, v, f, _ = m(video, q, iters=4)
+    assert maxdiff(c, g["on_coords"]) < 1e-3
+    assert maxdiff(logit(v), logit(g["on_vis"])) < 1e-4
+    assert maxdiff(logit(f), logit(g["on_conf"])) < 1e-4
+    m.init_video_online_processing()
+    for ind in range(0, video.shape[1] - 4, 4):
+        cs, vs, fs, _ = m(video[:, ind:ind + 8], q, iters=4, is_online=True)
+    assert maxdiff(cs, g["on_stream_coords"]) < 1e-3
+    assert maxdiff(logit(vs), logit(g["on_stream_vis"])) < 1e-4
+    assert maxdiff(logit(fs), logit(g["on_stream_conf"])) < 1e-4
+    # reference self-consistency: streaming == sliding exactly
+    assert maxdiff(cs, c) == 0.0
+
+
+def test_model_offline(golden):
+    from cotracker_amd.model import CoTrackerThreeOffline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_offline")
+    m = CoTrackerThreeOffline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=2)
+    m = m.to(dev())
+    c, v, f, _ = m(t(g["off_video"]), t(g["off_queries"]), iters=4)
+    assert maxdiff(c, g["off_coords"]) < 1e-3
+    assert maxdiff(logit(v), logit(g["off_vis"])) < 1e-4
+    assert maxdiff(logit(f), logit(g["off_conf"])) < 1e-4
+
+
+def test_predictors(golden):
+    from cotracker_amd.predictor import CoTrackerPredictor, CoTrackerOnlinePredictor
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("predictor")
+    video = t(g["video"])
+    p = CoTrackerPredictor(checkpoint=None, offline=True, window_len=60)
+    fill_synthetic_(p.model, seed=4)
+    p = p.to(dev())
+    tr, vi = p(video, grid_size=4)
+    assert maxdiff(tr, g["offline_grid_tracks"]) < 1e-3
+    assert (vi.cpu().numpy() != g["offline_grid_vis"]).mean() < 0.01
+    q = t(g["queries"])
+    tr, vi = p(video, queries=q)
+    assert maxdiff(tr, g["offline_q_tracks"]) < 1e-3
+    tr, vi = p(video, queries=q, backward_tracking=True)
+    assert maxdiff(tr, g["offline_qb_tracks"]) < 1e-3
+
+    p = CoTrackerPredictor(checkpoint=None, offline=False, window_len=8)
+    fill_synthetic_(p.model, seed=5)
+    p = p.to(dev())
+    tr, vi = p(video, grid_size=4)
+    assert maxdiff(tr, g["sliding_grid_tracks"]) < 1e-3
+
+    p = CoTrackerOnlinePredictor(checkpoint=None, window_len=8)
+    fill_synthetic_(p.model, seed=5)
+    p = p.to(dev())
+    p(video_chunk=video, is_first_step=True, grid_size=4)
+    for ind in range(0, video.shape[1] - p.step, p.step):
+        tr, vi = p(video_chunk=video[:, ind:ind + p.step * 2])
+    assert maxdiff(tr, g["online_grid_tracks"]) < 1e-3
+    assert (vi.cpu().numpy() != g["online_grid_vis"]).mean() < 0.01
+
+
+def test_full_size_properties():
+    """Size-independent properties at C3's window shape (S=16, N=6400): determinism, independence of
+    the point-chunking of the correlation stage, and zero update for masked-off support."""
+    from cotracker_amd import ops
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=16).eval()
+    fill_synthetic_(m, seed=0)
+    m = m.to(dev())
+    pw = m.packed(dev())
+    S, N = 16, 6400
+    g = torch.Generator(device="cpu").manual_seed(0)
+    f0 = torch.randn(S, 96, 128, 128, generator=g).to(dev())
+    f0 = f0 / f0.norm(dim=-1, keepdim=True)
+    pyr = ops.build_pyramid(f0.contiguous())
+    qc = (torch.rand(N, 2, generator=g) * torch.tensor([127.0, 95.0])).to(dev())
+    sup = [ops.sample_support(pyr[l], torch.zeros(N, device=dev()), (qc / 2 ** l).contiguous()) for l in range(4)]
+
+    def run(rows):
+        coords = qc[None].expand(S, N, 2).contiguous()
+        vis, conf = torch.zeros(S, N, device=dev()), torch.zeros(S, N, device=dev())
+        win = ops.Window(pyr, sup, coords, vis, conf, (128.0, 96.0), iters=2, max_corr_rows=rows)
+        ops.forward_window(win, pw)
+        return coords, vis, conf
+
+    a = run(262144)
+    b = run(262144)
+    c = run(16 * 1000)
+    for x, y in zip(a, b):
+        assert maxdiff(x, y) == 0.0          # run-to-run determinism
+    for x, y in zip(a, c):
+        assert maxdiff(x, y) == 0.0          # chunking of the correlation stage does not change results
+    assert torch.isfinite(a[0]).all() and float((a[0] - qc[None]).abs().max()) > 1e-3
