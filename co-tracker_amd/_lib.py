@@ -59,6 +59,7 @@ class GemmArgs(C.Structure):
         ("resid", _fp), ("ldr", C.c_int64),
         ("act", C.c_int32),
         ("batch", C.c_int32), ("a_bs", C.c_int64), ("c_bs", C.c_int64),
+        ("k_valid", C.c_int32),
     ]
 
 
@@ -70,6 +71,11 @@ class AttnArgs(C.Structure):
         ("nbatch", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
         ("splits", C.c_int32), ("partial", _fp),
     ]
+
+
+class ProfileRow(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
 
 
 # every symbol include/ctk.h declares: (restype, argtypes)
@@ -93,6 +99,8 @@ SYMBOLS = {
     "ctk_gemm": (C.c_int, [_P(GemmArgs), _fp]),
     "ctk_layernorm": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, C.c_float, _fp]),
     "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
+    "ctk_profile_enable": (C.c_int, [C.c_int]),
+    "ctk_profile_read": (C.c_int, [_P(ProfileRow), C.c_int, _P(C.c_int)]),
 }
 
 _lib = None
@@ -107,6 +115,11 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (or `make -C co-tracker_amd/csrc`).  There is no CPU fallback.")
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be mapped BEFORE our
+    # library so that both share ONE HIP runtime; loaded the other way round the process ends up
+    # with two runtimes and ours sees no device (hipErrorNoDevice).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

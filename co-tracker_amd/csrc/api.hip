@@ -20,11 +20,11 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int gemm(const float* A, long lda, int M, const float* W, long ldw, int N, int K, float* C, long ldc, const float* bias,
          int act, const float* resid, long ldr, hipStream_t s, const float* bias_rows = nullptr, int period = 0,
-         int batch = 1, long a_bs = 0, long c_bs = 0) {
+         int batch = 1, long a_bs = 0, long c_bs = 0, int k_valid = 0) {
   ctk_gemm_args g;
   g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
   g.bias = bias; g.bias_rows = bias_rows; g.bias_period = period; g.resid = resid; g.ldr = ldr; g.act = act;
-  g.batch = batch; g.a_bs = a_bs; g.c_bs = c_bs;
+  g.batch = batch; g.a_bs = a_bs; g.c_bs = c_bs; g.k_valid = k_valid;
   return ctk_gemm(&g, s);
 }
 
@@ -174,7 +174,7 @@ int check_weights(const ctk_model_weights* w) {
 int input_projection(int S, int N, const float* x, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
   // tokens = input_transform(x + time_emb)   (cotracker3_online.py:247, cotracker.py:484)
   return gemm(x, CTK_X_LD, N * S, w->in_w, CTK_X_LD, CTK_HID, CTK_X_LD, ws.tokens, CTK_HID, nullptr, CTK_ACT_NONE, nullptr, 0,
-              s, w->in_bias_t, S);
+              s, w->in_bias_t, S, 1, 0, 0, CTK_X_DIM);
 }
 
 // ---- corr_embed workspace -------------------------------------------------------------------
@@ -213,7 +213,7 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
     CTK_TRY(ctk_launch_corr_volume(a, n0, cnt, ws.vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
     // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
     CTK_TRY(gemm(ws.vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), w->corr_fc1_w, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, ws.h1, CTK_HID,
-                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s));
+                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s, nullptr, 0, 1, 0, 0, CTK_CORR_K));
     // corr_mlp.fc2, one batch per level, written into x[n*S+t][l*256 ...]   (torch.cat :209)
     CTK_TRY(gemm(ws.h1, CTK_HID, (int)rows, w->corr_fc2_w, CTK_HID, 256, CTK_HID, x + (long)n0 * a->S * CTK_X_LD + CTK_X_CORR,
                  CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256));

@@ -13,6 +13,7 @@
 // of the [(N+64), S, 384] token tensor are both reached without the reference's
 // permute+contiguous copies (cotracker.py:494,504,520).
 #include "ctk_common.h"
+#include "ctk_profile.h"
 
 namespace {
 
@@ -200,6 +201,8 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
     gx = (unsigned)((a->nbatch + p.bpw - 1) / p.bpw);
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  CtkProfScope ps("attention", 4.0 * a->nbatch * (double)a->n1 * a->n2 * CTK_HID,
+                  4.0 * a->nbatch * ((double)a->n1 * 2 + (double)a->n2 * 2) * CTK_HID, s);
   const size_t lds_bytes = (size_t)2 * p.bpw * (KC * HD + BPAD) * sizeof(float);
   hipLaunchKernelGGL(attention_kernel, dim3(gx, CTK_HEADS, (unsigned)p.splits), dim3(64), lds_bytes, s, p);
   CTK_HIP_CHECK_LAUNCH();

@@ -18,6 +18,7 @@
 // D (16 rows x 64 cols, cols 49..63 dropped) goes to the correlation buffer row (l, n, t),
 // column p*49+q  ==  the reference's (h,w,i,j) row-major flattening (:205).
 #include "ctk_common.h"
+#include "ctk_profile.h"
 
 namespace {
 
@@ -316,6 +317,10 @@ int ctk_launch_corr_volume(const ctk_window_args* a, int n0, int ncount, float* 
   p.ncount = ncount;
   p.tchunks = (a->S + TC - 1) / TC;
   const long blocks = (long)ncount * CTK_LEVELS * p.tchunks;
+  // algorithmic work per (t,n,level): 2*49*49*128 flop; (2r+2)^2*128*4 B footprint + support/S + volume out
+  const double units = (double)ncount * a->S * CTK_LEVELS;
+  CtkProfScope ps("corr_volume", units * 2.0 * 49 * 49 * 128,
+                  units * (64.0 * 128 * 4 + 49.0 * 128 * 4 / a->S + 2.0 + 2401.0 * 4), s);
   hipLaunchKernelGGL(corr_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;

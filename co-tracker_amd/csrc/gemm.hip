@@ -14,6 +14,7 @@
 // One barrier per K-tile (double-buffered LDS); global loads for tile k+1 are issued
 // before the MFMAs of tile k.
 #include "ctk_common.h"
+#include "ctk_profile.h"
 
 namespace {
 
@@ -159,14 +160,19 @@ extern "C" int ctk_gemm(const ctk_gemm_args* a, void* stream) {
   g.resid = a->resid; g.ldr = a->ldr; g.act = a->act;
   g.batch = batch; g.a_bs = a->a_bs; g.c_bs = a->c_bs;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const double kv = (double)(a->k_valid > 0 ? a->k_valid : a->K);
+  const double flops = 2.0 * a->M * (double)a->N * kv * batch;
+  const double bytes = 4.0 * batch * ((double)a->M * kv + (double)a->M * a->N * (a->resid ? 2.0 : 1.0)) + 4.0 * a->N * kv;
   // 128x128 tiles when they fill the chip, 64x64 tiles for the small (virtual-track) GEMMs.
   const long big_blocks = (long)((a->M + 127) / 128) * (a->N / 128) * batch;
   if ((a->N % 128) == 0 && big_blocks >= 384) {
     g.mblocks = (a->M + 127) / 128; g.nblocks = a->N / 128;
+    CtkProfScope ps("gemm_f32_128x128", flops, bytes, s);
     hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), dim3((unsigned)big_blocks), dim3(256), 0, s, g);
   } else {
     g.mblocks = (a->M + 63) / 64; g.nblocks = a->N / 64;
     const long blocks = (long)g.mblocks * g.nblocks * batch;
+    CtkProfScope ps("gemm_f32_64x64", flops, bytes, s);
     hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   }
   CTK_HIP_CHECK_LAUNCH();

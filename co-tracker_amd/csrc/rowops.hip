@@ -1,6 +1,7 @@
 // Row-wise kernels of the update iteration: LayerNorm, token assembly (posenc), virtual-token
 // broadcast and the output heads fused with the (coords, vis, conf) state update.
 #include "ctk_common.h"
+#include "ctk_profile.h"
 
 namespace {
 
@@ -142,6 +143,7 @@ extern "C" int ctk_layernorm(const float* x, float* y, int64_t R, const float* g
   if (!x || !y) return CTK_E_NULL;
   if (R <= 0) return CTK_E_SHAPE;
   if ((gamma == nullptr) != (beta == nullptr)) return CTK_E_NULL;
+  CtkProfScope ps("layernorm", 8.0 * R * CTK_HID, 8.0 * R * CTK_HID, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      y, (long)R, gamma, beta, eps);
   CTK_HIP_CHECK_LAUNCH();
@@ -152,6 +154,7 @@ extern "C" int ctk_assemble_tokens(const ctk_window_args* a, float* x, void* str
   if (!a || !a->coords || !a->vis || !a->conf || !x) return CTK_E_NULL;
   if (a->S <= 0 || a->N <= 0 || !(a->scale_x > 0.f) || !(a->scale_y > 0.f)) return CTK_E_SHAPE;
   const long total = (long)a->S * a->N * (CTK_X_LD - CTK_X_VIS);
+  CtkProfScope ps("assemble_tokens", 0.0, 4.0 * total, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a->coords, a->vis, a->conf, a->S, a->N, a->scale_x, a->scale_y, x);
   CTK_HIP_CHECK_LAUNCH();
@@ -160,6 +163,7 @@ extern "C" int ctk_assemble_tokens(const ctk_window_args* a, float* x, void* str
 
 int ctk_launch_virtual_init(const float* vt, int S, float* dst, hipStream_t s) {
   const long total = (long)CTK_VIRT * S * (CTK_HID / 4);
+  CtkProfScope ps("virtual_init", 0.0, 16.0 * total, s);
   hipLaunchKernelGGL(virtual_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, vt, S, dst);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
@@ -168,6 +172,7 @@ int ctk_launch_virtual_init(const float* vt, int S, float* dst, hipStream_t s) {
 int ctk_launch_heads(const float* tokens, const float* hw, const float* hb, int S, int N, float* delta, float* coords,
                      float* vis, float* conf, hipStream_t s) {
   const long rows = (long)S * N;
+  CtkProfScope ps("heads_update", 8.0 * rows * CTK_HID, 4.0 * rows * CTK_HID, s);
   hipLaunchKernelGGL(heads_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tokens, hw, hb, S, N, delta, coords,
                      vis, conf);
   CTK_HIP_CHECK_LAUNCH();

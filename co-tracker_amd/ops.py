@@ -35,7 +35,10 @@ def _chk_f32(*ts):
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, act: int = L.ACT_NONE, resid=None, bias_rows=None,
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + bias_rows[m % period]) + resid."""
-    _chk_f32(a, w, bias, resid, bias_rows, out)
+    _chk_f32(a, w, bias, bias_rows)
+    for t_ in (resid, out):  # row-strided views are fine (leading dimension is passed explicitly)
+        if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.stride(1) == 1):
+            raise ValueError("out/resid must be float32 device tensors with unit column stride")
     M, K = a.shape
     N = w.shape[0]
     if out is None:
@@ -49,7 +52,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, act: int = L.ACT_NONE, res
     g.bias_period = bias_rows.shape[0] if bias_rows is not None else 0
     g.resid, g.ldr = _ptr(resid), (resid.stride(0) if resid is not None else 0)
     g.act = act
-    g.batch, g.a_bs, g.c_bs = 1, 0, 0
+    g.batch, g.a_bs, g.c_bs, g.k_valid = 1, 0, 0, 0
     L.check(L.load().ctk_gemm(C.byref(g), _stream()), "ctk_gemm")
     return out
 
@@ -229,3 +232,18 @@ def update_former(x: torch.Tensor, S: int, N: int, weights) -> torch.Tensor:
     mw = weights.struct_for(S)
     L.check(lib.ctk_update_former(S, N, _ptr(x), C.byref(mw), _ptr(delta), _ptr(ws), ws.numel(), _stream()), "ctk_update_former")
     return delta
+
+
+# ------------------------------------------------------------------------------------------
+# opt-in per-kernel timing (bench.py)
+# ------------------------------------------------------------------------------------------
+def profile_enable(on: bool) -> None:
+    L.check(L.load().ctk_profile_enable(1 if on else 0), "ctk_profile_enable")
+
+
+def profile_read():
+    rows = (L.ProfileRow * 64)()
+    n = C.c_int(0)
+    L.check(L.load().ctk_profile_read(rows, 64, C.byref(n)), "ctk_profile_read")
+    return [dict(name=rows[i].name.decode(), launches=rows[i].launches, total_ms=rows[i].total_ms, flops=rows[i].flops,
+                 bytes=rows[i].bytes) for i in range(n.value)]

@@ -1,0 +1,68 @@
+"""Multi-GPU sharding of query points: one process per GPU, contiguous chunks of the
+query list tracked independently (exactly what the reference's dense mode does in sequence,
+predictor.py:80-96), then ONE all-gather of the final (tracks, visibility) over RCCL/xGMI.
+
+Every stage of the update is per-(frame, point) except the space attention, where the 64 virtual
+tracks attend over all points of a call -- so a sharded run equals the reference run *on the same
+chunks* (not the joint run; they differ by ~1e-3 px even at random init).
+There is no collective on the data path itself; the encoder is replicated on every rank.
+"""
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def chunk_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous chunk [lo, hi) of rank `rank`: ceil(n/world) points each, last ranks may be short/empty."""
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def shard_queries(queries: torch.Tensor, world: int, rank: int) -> torch.Tensor:
+    """queries [B,N,3] -> this rank's contiguous chunk [B,n_r,3]."""
+    lo, hi = chunk_bounds(queries.shape[1], world, rank)
+    return queries[:, lo:hi]
+
+
+def all_gather_tracks(tracks: torch.Tensor, vis: torch.Tensor, n_total: int, group=None):
+    """tracks [B,T,n_r,2], vis [B,T,n_r] of this rank -> ([B,T,N,2], [B,T,N]) on every rank.
+
+    Chunks are padded to ceil(N/world) so a single fixed-size all_gather (ncclAllGather under the
+    "nccl" backend = RCCL) suffices; on the fully connected xGMI topology that is one hop per peer.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return tracks, vis
+    per = (n_total + world - 1) // world
+    B, T = tracks.shape[:2]
+    packed = torch.zeros(B, T, per, 3, device=tracks.device, dtype=torch.float32)
+    n_r = tracks.shape[2]
+    packed[:, :, :n_r, :2] = tracks
+    packed[:, :, :n_r, 2] = vis.to(torch.float32)
+    out = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(out, packed.contiguous(), group=group)
+    full = torch.cat(out, dim=2)[:, :, :n_total]
+    vis_full = full[..., 2]
+    if vis.dtype == torch.bool:
+        vis_full = vis_full > 0.5
+    return full[..., :2].contiguous(), vis_full
+
+
+def track_sharded(predictor, video: torch.Tensor, queries: torch.Tensor, group=None, **kwargs):
+    """Track `queries` [B,N,3] with the points sharded over the ranks of `group`.
+
+    `predictor` is any callable with CoTrackerPredictor.forward's signature.  Returns the full
+    ([B,T,N,2], [B,T,N]) on every rank.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = shard_queries(queries, world, rank)
+    if mine.shape[1] > 0:
+        tracks, vis = predictor(video, queries=mine, **kwargs)
+    else:  # more ranks than points
+        B, T = video.shape[:2]
+        tracks = torch.zeros(B, T, 0, 2, device=video.device)
+        vis = torch.zeros(B, T, 0, device=video.device, dtype=torch.bool)
+    return all_gather_tracks(tracks, vis, queries.shape[1], group)

@@ -174,6 +174,7 @@ typedef struct ctk_gemm_args {
   const float* resid; int64_t ldr;
   int32_t act;
   int32_t batch; int64_t a_bs; int64_t c_bs;
+  int32_t k_valid;         /* non-padding columns of K (0 = K); only used for flop accounting */
 } ctk_gemm_args;
 int ctk_gemm(const ctk_gemm_args* g, void* stream);
 
@@ -192,6 +193,22 @@ typedef struct ctk_attn_args {
   float* partial;          /* [splits, nbatch, 8, n1, 50] or NULL    */
 } ctk_attn_args;
 int ctk_attention(const ctk_attn_args* a, void* stream);
+
+/* ---- opt-in kernel timing (bench.py) ------------------------------------------------
+ * When enabled, every kernel launch of this library is bracketed by two HIP events recorded on
+ * the launch stream; ctk_profile_read synchronises them and returns one row per kernel with the
+ * launch count, summed duration and the summed ALGORITHMIC flops/bytes of those launches.
+ * Bench-only: the recorder is process-global and not thread safe (the one exception to the
+ * "no mutable global state" rule above; it is off by default).                              */
+typedef struct ctk_profile_row {
+  char name[32];
+  int64_t launches;
+  double total_ms;
+  double flops;
+  double bytes;
+} ctk_profile_row;
+int ctk_profile_enable(int on);
+int ctk_profile_read(ctk_profile_row* rows, int max_rows, int* nrows);
 
 #ifdef __cplusplus
 }

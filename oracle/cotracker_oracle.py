@@ -78,9 +78,12 @@ def bilinear_sampler_5d(inp, coords):
     xi, wx0, wx1 = sampler_indices_weights(coords[..., 1], W)
     yi, wy0, wy1 = sampler_indices_weights(coords[..., 2], H)
     out = np.zeros((B, C) + coords.shape[1:-1], dtype=f32)
+    cl = np.ascontiguousarray(np.moveaxis(inp, 1, -1))  # channel-last copy: gathers read contiguous rows
     for b in range(B):
-        acc = np.zeros((C,) + coords.shape[1:-1], dtype=f32)
+        acc = np.zeros(coords.shape[1:-1] + (C,), dtype=f32)
         for dz, wz in ((0, wz0), (1, wz1)):
+            if dz == 1 and D == 1:
+                continue  # z1 = 1 > D-1: corner out of range, skipped by ATen
             for dy, wy in ((0, wy0), (1, wy1)):
                 for dx, wx in ((0, wx0), (1, wx1)):
                     X = xi[b] + dx
@@ -88,10 +91,9 @@ def bilinear_sampler_5d(inp, coords):
                     Z = zi[b] + dz
                     ok = (X <= W - 1) & (Y <= H - 1) & (Z <= D - 1)
                     w = ((wx[b] * wy[b]).astype(f32) * wz[b]).astype(f32)
-                    v = inp[b][:, np.minimum(Z, D - 1), np.minimum(Y, H - 1),
-                               np.minimum(X, W - 1)]
-                    acc = np.where(ok, (acc + (v * w).astype(f32)).astype(f32), acc)
-        out[b] = acc
+                    v = cl[b][np.minimum(Z, D - 1), np.minimum(Y, H - 1), np.minimum(X, W - 1)]
+                    acc = np.where(ok[..., None], (acc + (v * w[..., None]).astype(f32)).astype(f32), acc)
+        out[b] = np.moveaxis(acc, -1, 0)
     return out
 
 
@@ -169,7 +171,7 @@ def corr_volume(corr_feat, support):
     C = corr_feat.shape[-1]
     a = np.asarray(corr_feat, dtype=f32).reshape(B, T, N, 49, C)
     s = np.transpose(np.asarray(support, dtype=f32), (0, 2, 1, 3))  # [B,N,49,C]
-    vol = np.einsum("btnpc,bnqc->btnpq", a, s, optimize=True).astype(f32)
+    vol = np.matmul(a, np.swapaxes(s, -1, -2)[:, None]).astype(f32)  # [B,T,N,49,49] (BLAS)
     return vol.reshape(B, T, N, 49 * 49)
 
 
