@@ -11,10 +11,11 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     for tag in ("gemm_f32_kernel<2, 2>", "gemm_f32_kernel<1, 1>"):
         if tag in name:
             return tag
+    name = name.split("(")[0]
     return name[-70:]
 
 
