@@ -101,6 +101,7 @@ SYMBOLS = {
     "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
     "ctk_profile_enable": (C.c_int, [C.c_int]),
     "ctk_profile_read": (C.c_int, [_P(ProfileRow), C.c_int, _P(C.c_int)]),
+    "ctk_probe_mfma": (C.c_int, [C.c_int, C.c_int, _fp, _P(C.c_double), _fp]),
 }
 
 _lib = None

@@ -80,54 +80,88 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(CorrP p) {
   const float* fm = p.fmaps[lvl];
   const int li = lane & 15, g = lane >> 4;
 
+  // Software pipeline over (m-tile, channel-quarter) steps: the 8 corner float4 of the NEXT step are
+  // in flight while the current step blends + feeds 32 MFMAs, so the matrix pipe does not wait on
+  // the gather.  Two small register buffers alternate statically (quarters 0,2 -> buf0; 1,3 -> buf1).
   const int mtiles = (rows + 15) >> 4;
-  for (int mt = wave; mt < mtiles; mt += 4) {
-    const int r = mt * 16 + li;
-    const bool rv = r < rows;
-    const int rr = rv ? r : rows - 1;
+  struct Row {
+    unsigned o00, o10, o01, o11;  // element offsets of the four corners (incl. frame and lane-group offset)
+    float w00, w10, w01, w11;
+    bool valid;
+  };
+  auto setup = [&](int mt) {
+    Row r;
+    const int ri = mt * 16 + li;
+    r.valid = ri < rows;
+    const int rr = r.valid ? ri : rows - 1;
     const int tl = rr / CTK_TAPS, pp = rr - tl * CTK_TAPS;
     const int hx = pp / 7, wy = pp - hx * 7;  // first 7-index = x offset, second = y (cotracker3_online.py:102-104)
     const float* cptr = p.coords + ((long)(t0 + tl) * p.N + n) * 2;
     const float cx = __fmul_rn(cptr[0], inv), cy = __fmul_rn(cptr[1], inv);
     const CtkTap tx = ctk_tap(__fadd_rn(cx, (float)(hx - 3)), W, sx);
     const CtkTap ty = ctk_tap(__fadd_rn(cy, (float)(wy - 3)), H, sy);
-    const float w00 = __fmul_rn(tx.w0, ty.w0), w10 = __fmul_rn(tx.w1, ty.w0);
-    const float w01 = __fmul_rn(tx.w0, ty.w1), w11 = __fmul_rn(tx.w1, ty.w1);
-    const float* frame = fm + (long)(t0 + tl) * H * W * CTK_C + g * 4;
-    const float* p00 = frame + ((long)ty.i0 * W + tx.i0) * CTK_C;
-    const float* p10 = frame + ((long)ty.i0 * W + tx.i1) * CTK_C;
-    const float* p01 = frame + ((long)ty.i1 * W + tx.i0) * CTK_C;
-    const float* p11 = frame + ((long)ty.i1 * W + tx.i1) * CTK_C;
-
-    f32x4 acc[4];
+    r.w00 = __fmul_rn(tx.w0, ty.w0); r.w10 = __fmul_rn(tx.w1, ty.w0);
+    r.w01 = __fmul_rn(tx.w0, ty.w1); r.w11 = __fmul_rn(tx.w1, ty.w1);
+    const unsigned fo = (unsigned)(t0 + tl) * (unsigned)(H * W) ;
+    r.o00 = (fo + (unsigned)(ty.i0 * W + tx.i0)) * CTK_C + g * 4;
+    r.o10 = (fo + (unsigned)(ty.i0 * W + tx.i1)) * CTK_C + g * 4;
+    r.o01 = (fo + (unsigned)(ty.i1 * W + tx.i0)) * CTK_C + g * 4;
+    r.o11 = (fo + (unsigned)(ty.i1 * W + tx.i1)) * CTK_C + g * 4;
+    return r;
+  };
+  struct Buf { f32x4 v[2][4]; };  // [j within quarter][corner]
+  auto gather = [&](const Row& r, int quarter, Buf& bf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    for (int j = 0; j < 2; ++j) {
+      const unsigned off = (quarter * 2 + j) * 16;
+      bf.v[j][0] = *reinterpret_cast<const f32x4*>(fm + r.o00 + off);
+      bf.v[j][1] = *reinterpret_cast<const f32x4*>(fm + r.o10 + off);
+      bf.v[j][2] = *reinterpret_cast<const f32x4*>(fm + r.o01 + off);
+      bf.v[j][3] = *reinterpret_cast<const f32x4*>(fm + r.o11 + off);
+    }
+  };
+  f32x4 acc[4];
+  auto consume = [&](const Row& r, int quarter, const Buf& bf) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const f32x4 v00 = *reinterpret_cast<const f32x4*>(p00 + j * 16);
-      const f32x4 v10 = *reinterpret_cast<const f32x4*>(p10 + j * 16);
-      const f32x4 v01 = *reinterpret_cast<const f32x4*>(p01 + j * 16);
-      const f32x4 v11 = *reinterpret_cast<const f32x4*>(p11 + j * 16);
+    for (int j = 0; j < 2; ++j) {
       f32x4 a;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        // ATen grid_sampler_3d order: (x0,y0),(x1,y0),(x0,y1),(x1,y1); plain mul + add, no FMA
-        float s = __fmul_rn(v00[e], w00);
-        s = __fadd_rn(s, __fmul_rn(v10[e], w10));
-        s = __fadd_rn(s, __fmul_rn(v01[e], w01));
-        s = __fadd_rn(s, __fmul_rn(v11[e], w11));
-        a[e] = rv ? s : 0.0f;
+        // corner order of ATen grid_sampler_3d: (x0,y0),(x1,y0),(x0,y1),(x1,y1).  The fused path may
+        // use FMA here (values feed a 128-term dot product anyway); the standalone sampler
+        // (sample_patches_kernel) keeps the bit-exact mul+add sequence.
+        float s_ = bf.v[j][0][e] * r.w00;
+        s_ = fmaf(bf.v[j][1][e], r.w10, s_);
+        s_ = fmaf(bf.v[j][2][e], r.w01, s_);
+        s_ = fmaf(bf.v[j][3][e], r.w11, s_);
+        a[e] = r.valid ? s_ : 0.0f;
       }
       f32x4 b[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        b[q] = *reinterpret_cast<const f32x4*>(&sup[(q * 16 + li) * SUP_PITCH + j * 16 + g * 4]);
+        b[q] = *reinterpret_cast<const f32x4*>(&sup[(q * 16 + li) * SUP_PITCH + (quarter * 2 + j) * 16 + g * 4]);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[q][e], acc[q], 0, 0, 0);
     }
+  };
+
+  Buf buf0, buf1;
+  Row cur = setup(min(wave, mtiles - 1));
+  if (wave < mtiles) gather(cur, 0, buf0);
+  for (int mt = wave; mt < mtiles; mt += 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gather(cur, 1, buf1);
+    consume(cur, 0, buf0);
+    gather(cur, 2, buf0);
+    consume(cur, 1, buf1);
+    gather(cur, 3, buf1);
+    consume(cur, 2, buf0);
+    const Row nxt = setup(min(mt + 4, mtiles - 1));
+    if (mt + 4 < mtiles) gather(nxt, 0, buf0);
+    consume(cur, 3, buf1);
 
     // D layout (16x16): col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -143,6 +177,7 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(CorrP p) {
         }
       }
     }
+    cur = nxt;
   }
 }
 

@@ -114,30 +114,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP g) {
         for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NR; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][e], fb[ni][e], acc[mi][ni], 0, 0, 0);
+            // operands swapped on purpose: D' = W_tile . A_tile^T, so a lane ends up with 4 CONSECUTIVE
+            // output columns (n) of one output row (m) per register quad -> float4 epilogue I/O
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni][e], fa[mi][e], acc[mi][ni], 0, 0, 0);
     }
     if (kt + 1 < KT) lstore(buf ^ 1);
     __syncthreads();
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue.  With the swapped operands the 32x32 accumulator holds D'[n][m]:
+  //   m (output row)    = lane & 31
+  //   n (output column) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // so registers 4q..4q+3 are output columns 8q + 4*half + 0..3 of row m: one float4 per quad.
+  // Residual values (which may alias C: in-place "x += f(x)") are loaded up front, all at once.
+  const bool has_res = g.resid != nullptr;
+  const float* Rz = has_res ? g.resid + (long)bz * g.c_bs : nullptr;
+  f32x4 res[MR][NR][4];
 #pragma unroll
   for (int mi = 0; mi < MR; ++mi) {
+    const int row = min(m0 + wm * 32 * MR + mi * 32 + r32, g.M - 1);
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 32 * NR + ni * 32 + q * 8 + half * 4;
+        res[mi][ni][q] = has_res ? *reinterpret_cast<const f32x4*>(Rz + (long)row * g.ldr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi) {
+    const int row = m0 + wm * 32 * MR + mi * 32 + r32;
+    const float* brow = g.bias_rows ? g.bias_rows + (long)(min(row, g.M - 1) % g.bias_period) * g.N : nullptr;
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) {
-      const int col = n0 + wn * 32 * NR + ni * 32 + r32;
-      const float bcol = g.bias ? g.bias[col] : 0.0f;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = m0 + wm * 32 * MR + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        if (row < g.M) {
-          float v = acc[mi][ni][reg] + bcol;
-          if (g.bias_rows) v += g.bias_rows[(long)(row % g.bias_period) * g.N + col];
-          if (g.act == CTK_ACT_GELU_ERF) v = ctk_gelu_erf(v);
-          else if (g.act == CTK_ACT_GELU_TANH) v = ctk_gelu_tanh(v);
-          if (g.resid) v += g.resid[(long)bz * g.c_bs + (long)row * g.ldr + col];
-          C[(long)row * g.ldc + col] = v;
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 32 * NR + ni * 32 + q * 8 + half * 4;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][q * 4 + e];
+        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+        if (brow) v += *reinterpret_cast<const f32x4*>(brow + col);
+        if (g.act == CTK_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_erf(v[e]);
+        } else if (g.act == CTK_ACT_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_tanh(v[e]);
         }
+        v += res[mi][ni][q];
+        if (row < g.M) *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = v;
       }
     }
   }
@@ -151,7 +177,9 @@ extern "C" int ctk_gemm(const ctk_gemm_args* a, void* stream) {
   if ((a->lda % 4) || (a->ldw % 4) || !ctk_aligned16(a->A) || !ctk_aligned16(a->W)) return CTK_E_ALIGN;
   if (a->bias_rows && a->bias_period <= 0) return CTK_E_SHAPE;
   const int batch = a->batch > 0 ? a->batch : 1;
-  if (batch > 1 && (a->a_bs % 4)) return CTK_E_ALIGN;
+  if (batch > 1 && ((a->a_bs % 4) || (a->c_bs % 4))) return CTK_E_ALIGN;
+  if ((a->ldc % 4) || !ctk_aligned16(a->C) || (a->resid && ((a->ldr % 4) || !ctk_aligned16(a->resid)))) return CTK_E_ALIGN;
+  if ((a->bias && !ctk_aligned16(a->bias)) || (a->bias_rows && !ctk_aligned16(a->bias_rows))) return CTK_E_ALIGN;
   GemmP g;
   g.A = a->A; g.lda = a->lda; g.M = a->M;
   g.W = a->W; g.ldw = a->ldw; g.N = a->N; g.K = a->K;

@@ -87,3 +87,59 @@ extern "C" int ctk_profile_read(ctk_profile_row* rows, int max_rows, int* nrows)
   *nrows = n;
   return CTK_OK;
 }
+
+// ---- MFMA peak probes (tools/bench_peak.py): register-only MFMA loops, 2 waves per SIMD ----------
+namespace {
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+typedef short pbf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void probe_mfma_f32_kernel(int iters, float* out) {
+  pf32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f + blockIdx.x * 1e-4f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.678f) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void probe_mfma_bf16_kernel(int iters, float* out) {
+  pf32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  pbf16x8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (short)(0x3f80 + threadIdx.x + e);
+    b[e] = (short)(0x3f00 + blockIdx.x % 64 + e);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.678f) out[0] = s;
+}
+}  // namespace
+
+// kind 0: v_mfma_f32_32x32x2_f32, kind 1: v_mfma_f32_32x32x16_bf16.  Returns the flop count launched.
+extern "C" int ctk_probe_mfma(int kind, int iters, float* scratch, double* flops, void* stream) {
+  if (!scratch || !flops || iters <= 0) return CTK_E_NULL;
+  const int blocks = 256 * 2;  // 2 workgroups of 4 waves per CU
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (kind == 0) {
+    hipLaunchKernelGGL(probe_mfma_f32_kernel, dim3(blocks), dim3(256), 0, s, iters, scratch);
+    *flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * (2.0 * 32 * 32 * 2);
+  } else {
+    hipLaunchKernelGGL(probe_mfma_bf16_kernel, dim3(blocks), dim3(256), 0, s, iters, scratch);
+    *flops = (double)blocks * 4 * iters * 4.0 * (2.0 * 32 * 32 * 16);
+  }
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}

@@ -209,6 +209,9 @@ typedef struct ctk_profile_row {
 } ctk_profile_row;
 int ctk_profile_enable(int on);
 int ctk_profile_read(ctk_profile_row* rows, int max_rows, int* nrows);
+/* Register-only MFMA loop (2 workgroups x 4 waves per CU) to calibrate the sustained peak of this
+ * chip under its power budget: kind 0 = v_mfma_f32_32x32x2_f32, 1 = v_mfma_f32_32x32x16_bf16.     */
+int ctk_probe_mfma(int kind, int iters, float* scratch, double* flops, void* stream);
 
 #ifdef __cplusplus
 }
