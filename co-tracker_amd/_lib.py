@@ -19,17 +19,19 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
+ABI_VERSION = 2
 
 _fp = C.c_void_p  # device pointers travel as integers
 
 
 class BlockWeights(C.Structure):
-    _fields_ = [(n, _fp) for n in ("wq", "bq", "wkv", "bkv", "wo", "bo", "w1", "b1", "w2", "b2", "ctx_gamma", "ctx_beta")]
+    _fields_ = [(n, _fp) for n in ("wq", "bq", "wkv", "bkv", "wo", "bo", "w1", "b1", "w2", "b2", "ctx_gamma", "ctx_beta",
+                                   "wq_p", "wkv_p", "wo_p", "w1_p", "w2_p")]
 
 
 class ModelWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("corr_fc1_w", "corr_fc1_b", "corr_fc2_w", "corr_fc2_b", "in_w", "in_bias_t",
-                                   "virtual_tokens", "head_w", "head_b")] + [
+                                   "virtual_tokens", "head_w", "head_b", "corr_fc1_p", "corr_fc2_p", "in_p")] + [
         ("time_blocks", BlockWeights * DEPTH),
         ("virtual2point", BlockWeights * DEPTH),
         ("virtual_self", BlockWeights * DEPTH),
@@ -53,6 +55,7 @@ class GemmArgs(C.Structure):
     _fields_ = [
         ("A", _fp), ("lda", C.c_int64), ("M", C.c_int32),
         ("W", _fp), ("ldw", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+        ("Wp", _fp),
         ("C", _fp), ("ldc", C.c_int64),
         ("bias", _fp),
         ("bias_rows", _fp), ("bias_period", C.c_int32),
@@ -97,6 +100,8 @@ SYMBOLS = {
     "ctk_normalize_to_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_avg_pool2_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_gemm": (C.c_int, [_P(GemmArgs), _fp]),
+    "ctk_pack_weight_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
+    "ctk_pack_weight": (C.c_int, [_fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_layernorm": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, C.c_float, _fp]),
     "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
     "ctk_profile_enable": (C.c_int, [C.c_int]),
@@ -126,7 +131,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.ctk_abi_version() != 1:
+    if lib.ctk_abi_version() != ABI_VERSION:
         raise RuntimeError("libctk_hip.so ABI version mismatch")
     _lib = lib
     return lib

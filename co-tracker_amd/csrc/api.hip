@@ -18,11 +18,17 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
     if (rc__) return rc__;   \
   } while (0)
 
-int gemm(const float* A, long lda, int M, const float* W, long ldw, int N, int K, float* C, long ldc, const float* bias,
+// A Linear's weight: torch-layout f32 and/or the ctk_pack_weight blob (preferred when present).
+struct WRef {
+  const float* w;
+  const void* p;
+};
+
+int gemm(const float* A, long lda, int M, WRef W, long ldw, int N, int K, float* C, long ldc, const float* bias,
          int act, const float* resid, long ldr, hipStream_t s, const float* bias_rows = nullptr, int period = 0,
          int batch = 1, long a_bs = 0, long c_bs = 0, int k_valid = 0) {
   ctk_gemm_args g;
-  g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
+  g.A = A; g.lda = lda; g.M = M; g.W = W.w; g.Wp = W.p; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
   g.bias = bias; g.bias_rows = bias_rows; g.bias_period = period; g.resid = resid; g.ldr = ldr; g.act = act;
   g.batch = batch; g.a_bs = a_bs; g.c_bs = c_bs; g.k_valid = k_valid;
   return ctk_gemm(&g, s);
@@ -83,13 +89,14 @@ int mlp_block(const UfWs& ws, long r0, long R, const ctk_block_weights& b, hipSt
   float* xn = ws.xn + r0 * CTK_HID;
   float* hid = ws.hid + r0 * CTK_MLP;
   CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, s));
-  CTK_TRY(gemm(xn, CTK_HID, (int)R, b.w1, CTK_HID, CTK_MLP, CTK_HID, hid, CTK_MLP, b.b1, CTK_ACT_GELU_TANH, nullptr, 0, s));
-  CTK_TRY(gemm(hid, CTK_MLP, (int)R, b.w2, CTK_MLP, CTK_HID, CTK_MLP, tok, CTK_HID, b.b2, CTK_ACT_NONE, tok, CTK_HID, s));
+  CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.w1, b.w1_p}, CTK_HID, CTK_MLP, CTK_HID, hid, CTK_MLP, b.b1, CTK_ACT_GELU_TANH, nullptr, 0, s));
+  CTK_TRY(gemm(hid, CTK_MLP, (int)R, WRef{b.w2, b.w2_p}, CTK_MLP, CTK_HID, CTK_MLP, tok, CTK_HID, b.b2, CTK_ACT_NONE, tok, CTK_HID, s));
   return CTK_OK;
 }
 
 int check_block(const ctk_block_weights& b, bool cross) {
-  if (!b.wq || !b.bq || !b.wkv || !b.bkv || !b.wo || !b.bo || !b.w1 || !b.b1 || !b.w2 || !b.b2) return CTK_E_NULL;
+  if (!b.bq || !b.bkv || !b.bo || !b.b1 || !b.b2) return CTK_E_NULL;
+  if ((!b.wq && !b.wq_p) || (!b.wkv && !b.wkv_p) || (!b.wo && !b.wo_p) || (!b.w1 && !b.w1_p) || (!b.w2 && !b.w2_p)) return CTK_E_NULL;
   if (cross && (!b.ctx_gamma || !b.ctx_beta)) return CTK_E_NULL;
   return CTK_OK;
 }
@@ -112,10 +119,10 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
     {
       const ctk_block_weights& b = w->time_blocks[i];
       CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, s));
-      CTK_TRY(gemm(xn, CTK_HID, (int)R, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn, CTK_HID, (int)R, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
       CTK_TRY(attn(qkv, QL, S, 1, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, S, 1, att, S, 1, N + CTK_VIRT, S, S, 1, nullptr, s));
-      CTK_TRY(gemm(att, CTK_HID, (int)R, b.wo, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
+      CTK_TRY(gemm(att, CTK_HID, (int)R, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
       CTK_TRY(mlp_block(ws, 0, R, b, s));
     }
     // ---- virtual <- points cross attention                          cotracker.py:510-512
@@ -123,12 +130,12 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
       const ctk_block_weights& b = w->virtual2point[i];
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, s));   // norm1(virtual)
       CTK_TRY(ctk_layernorm(tok, xn, P, b.ctx_gamma, b.ctx_beta, 1e-5f, s));                        // norm_context(points)
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn, CTK_HID, (int)P, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
       // batch = frame t; query i = virtual track (row P + i*S + t); key j = point (row j*S + t)
       CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S, CTK_VIRT, N,
                    v2p_splits(N), ws.partial, s));
-      CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, b.wo, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
+      CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
                    tok + P * CTK_HID, CTK_HID, s));
       CTK_TRY(mlp_block(ws, P, V, b, s));
     }
@@ -136,11 +143,11 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
     {
       const ctk_block_weights& b = w->virtual_self[i];
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, s));
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
       CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S,
                    CTK_VIRT, CTK_VIRT, 1, nullptr, s));
-      CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, b.wo, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
+      CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
                    tok + P * CTK_HID, CTK_HID, s));
       CTK_TRY(mlp_block(ws, P, V, b, s));
     }
@@ -149,10 +156,10 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
       const ctk_block_weights& b = w->point2virtual[i];
       CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, s));                                              // norm1(points)
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, s));           // norm_context(virtual)
-      CTK_TRY(gemm(xn, CTK_HID, (int)P, b.wq, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, b.wkv, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
       CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s));
-      CTK_TRY(gemm(att, CTK_HID, (int)P, b.wo, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
+      CTK_TRY(gemm(att, CTK_HID, (int)P, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
       CTK_TRY(mlp_block(ws, 0, P, b, s));
     }
   }
@@ -161,7 +168,7 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
 
 int check_weights(const ctk_model_weights* w) {
   if (!w) return CTK_E_NULL;
-  if (!w->in_w || !w->in_bias_t || !w->virtual_tokens || !w->head_w || !w->head_b) return CTK_E_NULL;
+  if ((!w->in_w && !w->in_p) || !w->in_bias_t || !w->virtual_tokens || !w->head_w || !w->head_b) return CTK_E_NULL;
   for (int i = 0; i < CTK_DEPTH; ++i) {
     CTK_TRY(check_block(w->time_blocks[i], false));
     CTK_TRY(check_block(w->virtual2point[i], true));
@@ -173,7 +180,7 @@ int check_weights(const ctk_model_weights* w) {
 
 int input_projection(int S, int N, const float* x, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
   // tokens = input_transform(x + time_emb)   (cotracker3_online.py:247, cotracker.py:484)
-  return gemm(x, CTK_X_LD, N * S, w->in_w, CTK_X_LD, CTK_HID, CTK_X_LD, ws.tokens, CTK_HID, nullptr, CTK_ACT_NONE, nullptr, 0,
+  return gemm(x, CTK_X_LD, N * S, WRef{w->in_w, w->in_p}, CTK_X_LD, CTK_HID, CTK_X_LD, ws.tokens, CTK_HID, nullptr, CTK_ACT_NONE, nullptr, 0,
               s, w->in_bias_t, S, 1, 0, 0, CTK_X_DIM);
 }
 
@@ -206,16 +213,16 @@ CorrWs carve_corr(const ctk_window_args* a, void* base) {
 }
 
 int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* x, const CorrWs& ws, hipStream_t s) {
-  if (!w->corr_fc1_w || !w->corr_fc1_b || !w->corr_fc2_w || !w->corr_fc2_b) return CTK_E_NULL;
+  if ((!w->corr_fc1_w && !w->corr_fc1_p) || !w->corr_fc1_b || (!w->corr_fc2_w && !w->corr_fc2_p) || !w->corr_fc2_b) return CTK_E_NULL;
   for (int n0 = 0; n0 < a->N; n0 += ws.chunk) {
     const int cnt = (a->N - n0 < ws.chunk) ? a->N - n0 : ws.chunk;
     const long rows = (long)cnt * a->S;
     CTK_TRY(ctk_launch_corr_volume(a, n0, cnt, ws.vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
     // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
-    CTK_TRY(gemm(ws.vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), w->corr_fc1_w, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, ws.h1, CTK_HID,
+    CTK_TRY(gemm(ws.vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), WRef{w->corr_fc1_w, w->corr_fc1_p}, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, ws.h1, CTK_HID,
                  w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s, nullptr, 0, 1, 0, 0, CTK_CORR_K));
     // corr_mlp.fc2, one batch per level, written into x[n*S+t][l*256 ...]   (torch.cat :209)
-    CTK_TRY(gemm(ws.h1, CTK_HID, (int)rows, w->corr_fc2_w, CTK_HID, 256, CTK_HID, x + (long)n0 * a->S * CTK_X_LD + CTK_X_CORR,
+    CTK_TRY(gemm(ws.h1, CTK_HID, (int)rows, WRef{w->corr_fc2_w, w->corr_fc2_p}, CTK_HID, 256, CTK_HID, x + (long)n0 * a->S * CTK_X_LD + CTK_X_CORR,
                  CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256));
   }
   return CTK_OK;

@@ -15,26 +15,15 @@
 // before the MFMAs of tile k.
 #include "ctk_common.h"
 #include "ctk_profile.h"
+#include "gemm_params.h"
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int PITCH = BK + 4;  // floats
 
-struct GemmP {
-  const float* A; long lda; int M;
-  const float* W; long ldw; int N; int K;
-  float* C; long ldc;
-  const float* bias;
-  const float* bias_rows; int bias_period;
-  const float* resid; long ldr;
-  int act;
-  int batch; long a_bs; long c_bs;
-  int mblocks, nblocks;
-};
-
 template <int MR, int NR>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP g) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(CtkGemmP g) {
   constexpr int BM = 64 * MR, BN = 64 * NR;
   constexpr int A_LD4 = BM / 32, W_LD4 = BN / 32;  // float4 loads per thread per K-tile
   __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * PITCH];
@@ -172,17 +161,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP g) {
 }  // namespace
 
 extern "C" int ctk_gemm(const ctk_gemm_args* a, void* stream) {
-  if (!a || !a->A || !a->W || !a->C) return CTK_E_NULL;
+  if (!a || !a->A || (!a->W && !a->Wp) || !a->C) return CTK_E_NULL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->N % 64) || (a->K % BK)) return CTK_E_SHAPE;
-  if ((a->lda % 4) || (a->ldw % 4) || !ctk_aligned16(a->A) || !ctk_aligned16(a->W)) return CTK_E_ALIGN;
+  if ((a->lda % 4) || !ctk_aligned16(a->A)) return CTK_E_ALIGN;
+  if (a->Wp ? !ctk_aligned16(a->Wp) : ((a->ldw % 4) || !ctk_aligned16(a->W))) return CTK_E_ALIGN;
   if (a->bias_rows && a->bias_period <= 0) return CTK_E_SHAPE;
   const int batch = a->batch > 0 ? a->batch : 1;
   if (batch > 1 && ((a->a_bs % 4) || (a->c_bs % 4))) return CTK_E_ALIGN;
   if ((a->ldc % 4) || !ctk_aligned16(a->C) || (a->resid && ((a->ldr % 4) || !ctk_aligned16(a->resid)))) return CTK_E_ALIGN;
   if ((a->bias && !ctk_aligned16(a->bias)) || (a->bias_rows && !ctk_aligned16(a->bias_rows))) return CTK_E_ALIGN;
-  GemmP g;
+  CtkGemmP g;
   g.A = a->A; g.lda = a->lda; g.M = a->M;
   g.W = a->W; g.ldw = a->ldw; g.N = a->N; g.K = a->K;
+  g.Wp = static_cast<const unsigned short*>(a->Wp);
   g.C = a->C; g.ldc = a->ldc;
   g.bias = a->bias; g.bias_rows = a->bias_rows; g.bias_period = a->bias_period;
   g.resid = a->resid; g.ldr = a->ldr; g.act = a->act;
@@ -191,6 +182,7 @@ extern "C" int ctk_gemm(const ctk_gemm_args* a, void* stream) {
   const double kv = (double)(a->k_valid > 0 ? a->k_valid : a->K);
   const double flops = 2.0 * a->M * (double)a->N * kv * batch;
   const double bytes = 4.0 * batch * ((double)a->M * kv + (double)a->M * a->N * (a->resid ? 2.0 : 1.0)) + 4.0 * a->N * kv;
+  if (g.Wp) return ctk_launch_gemm_f16x3(g, flops, bytes, s);  // split-half MFMA back end (gemm_f16x3.hip)
   // 128x128 tiles when they fill the chip, 64x64 tiles for the small (virtual-track) GEMMs.
   const long big_blocks = (long)((a->M + 127) / 128) * (a->N / 128) * batch;
   if ((a->N % 128) == 0 && big_blocks >= 384) {

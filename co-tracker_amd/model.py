@@ -89,6 +89,9 @@ class _UpdateFormerParams(nn.Module):  # cotracker.py:387-462
         self.space_virtual2point_blocks = nn.ModuleList([_CrossBlock(hidden) for _ in range(depth)])
 
 
+DEFAULT_PRECISION = "f16x3"  # Linear back end of newly built models ("f16x3" | "f32"), see CoTrackerThreeBase.precision
+
+
 def sincos_time_embed(dim: int, window_len: int) -> torch.Tensor:
     """get_1d_sincos_pos_embed_from_grid on linspace(0, W-1, W) (embeddings.py:59-84) -> [1,W,dim]."""
     omega = torch.arange(dim // 2, dtype=torch.double) / (dim / 2.0)
@@ -104,7 +107,11 @@ def sincos_time_embed(dim: int, window_len: int) -> torch.Tensor:
 class PackedWeights:
     """Contiguous fp32 device copies in the layouts the C-ABI wants, plus the ctypes struct."""
 
-    def __init__(self, model: "CoTrackerThreeBase", device):
+    def __init__(self, model: "CoTrackerThreeBase", device, precision: str = "f16x3"):
+        if precision not in ("f16x3", "f32"):
+            raise ValueError("precision must be 'f16x3' (split-half MFMA, default) or 'f32' (exact-f32 MFMA)")
+        self.precision = precision
+        split = precision == "f16x3"
         sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in model.state_dict().items()}
         self.device = device
         self.keep: List[torch.Tensor] = []
@@ -116,9 +123,19 @@ class PackedWeights:
             self.keep.append(t)
             return t.data_ptr()
 
+        def pack(t: torch.Tensor):
+            """ctk_pack_weight blob of a Linear weight (None in exact-f32 mode)."""
+            if not split:
+                return None
+            blob = ops.pack_weight(t.contiguous())
+            self.keep.append(blob)
+            return blob.data_ptr()
+
         fc1 = torch.zeros(384, L.CORR_LD, device=device)
         fc1[:, : L.CORR_K] = sd["corr_mlp.fc1.weight"]
         st.corr_fc1_w = hold(fc1)
+        st.corr_fc1_p = pack(fc1)
+        st.corr_fc2_p = pack(sd["corr_mlp.fc2.weight"])
         st.corr_fc1_b = hold(sd["corr_mlp.fc1.bias"])
         st.corr_fc2_w = hold(sd["corr_mlp.fc2.weight"])
         st.corr_fc2_b = hold(sd["corr_mlp.fc2.bias"])
@@ -132,6 +149,7 @@ class PackedWeights:
         in_w[:, 1024:1026] = w_ref[:, 0:2]
         in_w[:, 1026:1110] = w_ref[:, 1026:1110]
         st.in_w = hold(in_w)
+        st.in_p = pack(in_w)
         st.virtual_tokens = hold(sd[u + "virual_tracks"].reshape(64, 384))
         st.head_w = hold(torch.cat([sd[u + "flow_head.weight"], sd[u + "vis_conf_head.weight"]], dim=0))
         st.head_b = hold(torch.cat([sd[u + "flow_head.bias"], sd[u + "vis_conf_head.bias"]], dim=0))
@@ -144,6 +162,8 @@ class PackedWeights:
             b.wo, b.bo = hold(sd[a + "to_out.weight"]), hold(sd[a + "to_out.bias"])
             b.w1, b.b1 = hold(sd[prefix + "mlp.fc1.weight"]), hold(sd[prefix + "mlp.fc1.bias"])
             b.w2, b.b2 = hold(sd[prefix + "mlp.fc2.weight"]), hold(sd[prefix + "mlp.fc2.bias"])
+            b.wq_p, b.wkv_p, b.wo_p = pack(sd[a + "to_q.weight"]), pack(sd[a + "to_kv.weight"]), pack(sd[a + "to_out.weight"])
+            b.w1_p, b.w2_p = pack(sd[prefix + "mlp.fc1.weight"]), pack(sd[prefix + "mlp.fc2.weight"])
             if cross:
                 b.ctx_gamma = hold(sd[prefix + "norm_context.weight"])
                 b.ctx_beta = hold(sd[prefix + "norm_context.bias"])
@@ -204,6 +224,9 @@ class CoTrackerThreeBase(nn.Module):
         self.register_buffer("time_emb", sincos_time_embed(self.input_dim, window_len))
         self._packed: Optional[PackedWeights] = None
         self.max_corr_rows = 262144  # (point,frame) rows of correlation volume resident at once (~10 GB)
+        # arithmetic of the Linear layers: "f16x3" = split-half MFMA (3 f16 MFMAs per product, f32 accumulate,
+        # fp32-class accuracy at 5.3x the f32-MFMA ceiling), "f32" = exact-f32 MFMA.  Not a reference kwarg.
+        self.precision = DEFAULT_PRECISION
 
     # -- weights ------------------------------------------------------------------------
     def load_state_dict(self, *args, **kwargs):
@@ -215,8 +238,8 @@ class CoTrackerThreeBase(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def packed(self, device) -> PackedWeights:
-        if self._packed is None or self._packed.device != device:
-            self._packed = PackedWeights(self, device)
+        if self._packed is None or self._packed.device != device or self._packed.precision != self.precision:
+            self._packed = PackedWeights(self, device, self.precision)
         return self._packed
 
     def invalidate_packed_weights(self):

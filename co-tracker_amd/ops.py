@@ -32,9 +32,22 @@ def _chk_f32(*ts):
 # ------------------------------------------------------------------------------------------
 # primitives
 # ------------------------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """Split a torch-layout Linear weight [N,K] (K % 32 == 0) into the two-half blob of the split-half
+    GEMM back end (ctk_pack_weight).  Returns a uint8 device tensor that must outlive its users."""
+    _chk_f32(w)
+    N, K = w.shape
+    nbytes = C.c_size_t(0)
+    L.check(L.load().ctk_pack_weight_bytes(N, K, C.byref(nbytes)), "ctk_pack_weight_bytes")
+    blob = torch.empty(nbytes.value, device=w.device, dtype=torch.uint8)
+    L.check(L.load().ctk_pack_weight(_ptr(w), K, N, K, _ptr(blob), _stream()), "ctk_pack_weight")
+    return blob
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, act: int = L.ACT_NONE, resid=None, bias_rows=None,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + bias_rows[m % period]) + resid."""
+         out: Optional[torch.Tensor] = None, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + bias_rows[m % period]) + resid.
+    packed = pack_weight(w) selects the split-half (3 x f16 MFMA) back end; None the exact-f32 one."""
     _chk_f32(a, w, bias, bias_rows)
     for t_ in (resid, out):  # row-strided views are fine (leading dimension is passed explicitly)
         if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.stride(1) == 1):
@@ -46,6 +59,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, act: int = L.ACT_NONE, res
     g = L.GemmArgs()
     g.A, g.lda, g.M = _ptr(a), K, M
     g.W, g.ldw, g.N, g.K = _ptr(w), w.shape[1], N, K
+    g.Wp = _ptr(packed)
     g.C, g.ldc = _ptr(out), out.stride(0)
     g.bias = _ptr(bias)
     g.bias_rows = _ptr(bias_rows)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 1
+#define CTK_ABI_VERSION 2
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -78,6 +78,9 @@ typedef struct ctk_block_weights {
   const float* w1;   const float* b1;    /* mlp.fc1   [1536,384],[1536] blocks.py:61  */
   const float* w2;   const float* b2;    /* mlp.fc2   [384,1536],[384]  blocks.py:67  */
   const float* ctx_gamma; const float* ctx_beta; /* norm_context [384] (cotracker.py:540) or NULL for AttnBlock */
+  /* optional ctk_pack_weight blobs of wq/wkv/wo/w1/w2: when non-NULL that Linear runs on the
+   * split-half MFMA back end, when NULL on the exact-f32 one (then the f32 pointer must be set) */
+  const void* wq_p; const void* wkv_p; const void* wo_p; const void* w1_p; const void* w2_p;
 } ctk_block_weights;
 
 /* EfficientUpdateFormer (cotracker.py:387-531) + corr_mlp (cotracker3_online.py:84). */
@@ -93,6 +96,9 @@ typedef struct ctk_model_weights {
   const float* virtual_tokens; /* virual_tracks [64,384]        cotracker.py:416 */
   const float* head_w;       /* [4,384] = cat(flow_head.weight, vis_conf_head.weight)  cotracker.py:526-529 */
   const float* head_b;       /* [4] */
+  const void* corr_fc1_p;    /* optional ctk_pack_weight blobs of corr_fc1_w / corr_fc2_w / in_w (see ctk_block_weights) */
+  const void* corr_fc2_p;
+  const void* in_p;
   ctk_block_weights time_blocks[CTK_DEPTH];
   ctk_block_weights virtual2point[CTK_DEPTH];
   ctk_block_weights virtual_self[CTK_DEPTH];
@@ -163,11 +169,15 @@ int ctk_avg_pool2_nhwc(const float* in, int32_t F, int32_t H, int32_t W, float* 
 
 /* ---- primitives (exported for unit tests and reuse) ------------------------------ */
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N] + bias_rows[(m % period),N]) + resid[M,N]
- * fp32 MFMA (v_mfma_f32_32x32x2_f32).  N % 64 == 0, K % 32 == 0, lda/ldw % 4 == 0,
- * A and W 16-byte aligned.  batch > 1 repeats with element strides a_bs / c_bs (shared W). */
+ * N % 64 == 0, K % 32 == 0, lda/ldw % 4 == 0, A and W 16-byte aligned.  batch > 1 repeats with
+ * element strides a_bs / c_bs (shared W).  Two back ends for the same nn.Linear contract:
+ *   Wp == NULL : exact-f32 MFMA (v_mfma_f32_32x32x2_f32), W = torch layout [N,K] f32
+ *   Wp != NULL : split-half MFMA (3 x v_mfma_f32_32x32x16_f16 per product, f32 accumulate, ~2^-21
+ *                relative per product); Wp = blob written by ctk_pack_weight, W is ignored.      */
 typedef struct ctk_gemm_args {
   const float* A; int64_t lda; int32_t M;
   const float* W; int64_t ldw; int32_t N; int32_t K;
+  const void* Wp;
   float* C; int64_t ldc;
   const float* bias;
   const float* bias_rows; int32_t bias_period;
@@ -177,6 +187,11 @@ typedef struct ctk_gemm_args {
   int32_t k_valid;         /* non-padding columns of K (0 = K); only used for flop accounting */
 } ctk_gemm_args;
 int ctk_gemm(const ctk_gemm_args* g, void* stream);
+/* Split a torch-layout weight [N,K] (K % 32 == 0, row stride ldw) into the packed two-half form
+ * the split-half back end reads: 64-byte header {s, 1/s} (s = power of two, chosen on the device
+ * from max|W|) + [N][K/32][2][32] IEEE halves (hi, lo of s*W).  Done once per weight at load.   */
+int ctk_pack_weight_bytes(int32_t N, int32_t K, size_t* out_bytes);
+int ctk_pack_weight(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream);
 
 /* LayerNorm over 384 channels, rows [0,R): y = (x-mean)/sqrt(var+eps) [*gamma+beta].  */
 int ctk_layernorm(const float* x, float* y, int64_t R, const float* gamma, const float* beta,

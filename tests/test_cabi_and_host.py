@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SYMBOLS), f"binding/header mismatch: {declared ^ set(_lib.SYMBOLS)}"
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ctk_abi_version() == 1
+    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_argument_validation_without_gpu(lib):
@@ -56,8 +56,8 @@ def test_argument_validation_without_gpu(lib):
 
 def test_struct_sizes_match_header():
     from cotracker_amd import _lib as L
-    assert C.sizeof(L.BlockWeights) == 12 * 8
-    assert C.sizeof(L.ModelWeights) == 9 * 8 + 4 * 3 * 12 * 8
+    assert C.sizeof(L.BlockWeights) == 17 * 8
+    assert C.sizeof(L.ModelWeights) == 12 * 8 + 4 * 3 * 17 * 8
     assert C.sizeof(L.WindowArgs) == 48 + 8 * 8 + 8 + 24 + 16
     assert C.sizeof(L.ProfileRow) == 32 + 8 * 4
 

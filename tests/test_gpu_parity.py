@@ -49,14 +49,30 @@ def x_to_ours(x_ref):
     return x
 
 
-@pytest.fixture(scope="module")
-def ops_model():
+@pytest.fixture(autouse=True, params=["f16x3", "f32"])
+def precision(request):
+    """Every test runs on both Linear back ends: split-half MFMA (the default) and exact-f32 MFMA."""
+    from cotracker_amd import model
+    old = model.DEFAULT_PRECISION
+    model.DEFAULT_PRECISION = request.param
+    yield request.param
+    model.DEFAULT_PRECISION = old
+
+
+_ops_models = {}
+
+
+@pytest.fixture
+def ops_model(precision):
     """Online model with the synthetic weights the ops.npz goldens were made with."""
     from cotracker_amd.model import CoTrackerThreeOnline
     from cotracker_amd.weights import fill_synthetic_
-    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(96, 128)).eval()
-    fill_synthetic_(m, seed=3)
-    return m.to(dev())
+    if precision not in _ops_models:
+        m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(96, 128)).eval()
+        fill_synthetic_(m, seed=3)
+        assert m.precision == precision
+        _ops_models[precision] = m.to(dev())
+    return _ops_models[precision]
 
 
 def make_window(g, model, coords=None, vis=None, conf=None, iters=1, mask=None):
@@ -76,25 +92,44 @@ def make_window(g, model, coords=None, vis=None, conf=None, iters=1, mask=None):
 @pytest.mark.parametrize("M,K,N", [(1000, 384, 1152), (257, 2432, 384), (64, 1536, 384), (16500, 1120, 384),
                                    (20000, 384, 1536)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_gemm(M, K, N, act):
+def test_gemm(M, K, N, act, precision):
     from cotracker_amd import ops
+    split = precision == "f16x3"
     g = torch.Generator(device="cpu").manual_seed(M + K + N + act)
     a = torch.randn(M, K, generator=g).to(dev())
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev())
     bias = torch.randn(N, generator=g).to(dev())
     resid = torch.randn(M, N, generator=g).to(dev())
     brows = torch.randn(8, N, generator=g).to(dev())
-    out = ops.gemm(a, w, bias=bias, act=act, resid=resid, bias_rows=brows)
+    wp = ops.pack_weight(w) if split else None
+    out = ops.gemm(a, w, bias=bias, act=act, resid=resid, bias_rows=brows, packed=wp)
     ref = a.double() @ w.double().t() + bias.double() + brows.double()[torch.arange(M, device=dev()) % 8]
     if act == 1:
         ref = torch.nn.functional.gelu(ref)
     elif act == 2:
         ref = torch.nn.functional.gelu(ref, approximate="tanh")
     ref = ref + resid.double()
-    assert maxdiff(out, ref) < 2e-5
+    tol = 4e-5 if split else 2e-5  # |out| ~ 1..5; split-half products carry ~2^-21 relative error each
+    assert maxdiff(out, ref) < tol
     # transposition-detecting: plain product with asymmetric operands and no epilogue
-    out2 = ops.gemm(a, w)
-    assert maxdiff(out2, a.double() @ w.double().t()) < 2e-5
+    out2 = ops.gemm(a, w, packed=wp)
+    assert maxdiff(out2, a.double() @ w.double().t()) < tol
+
+
+@pytest.mark.parametrize("wscale", [1e-6, 1e-3, 1.0, 3e4])
+def test_gemm_split_half_weight_scaling(wscale):
+    """ctk_pack_weight rescales W by a power of two so tiny / huge weights keep ~21 significant bits."""
+    from cotracker_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = torch.randn(513, 384, generator=g).to(dev())
+    w = (torch.randn(256, 384, generator=g) * wscale).to(dev())
+    w[5] = 0.0
+    out = ops.gemm(a, w, packed=ops.pack_weight(w))
+    ref = a.double() @ w.double().t()
+    assert maxdiff(out, ref) < 3e-5 * wscale * 384 ** 0.5
+    assert float(out[:, 5].abs().max()) == 0.0
+    zero = torch.zeros(64, 384, device=dev())
+    assert float(ops.gemm(a, zero, packed=ops.pack_weight(zero)).abs().max()) == 0.0
 
 
 def test_gemm_inplace_residual_and_strided_out():
@@ -103,6 +138,9 @@ def test_gemm_inplace_residual_and_strided_out():
     a = torch.randn(300, 384, generator=g).to(dev())
     w = (torch.randn(256, 384, generator=g) / 20).to(dev())
     big = torch.zeros(300, 1120, device=dev())
+    ops.gemm(a, w, out=big[:, 256:512], packed=ops.pack_weight(w))
+    assert maxdiff(big[:, 256:512], a.double() @ w.double().t()) < 2e-5
+    big.zero_()
     ops.gemm(a, w, out=big[:, 256:512])
     assert maxdiff(big[:, 256:512], a.double() @ w.double().t()) < 2e-5
     assert float(big[:, :256].abs().max()) == 0 and float(big[:, 512:].abs().max()) == 0

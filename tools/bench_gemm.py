@@ -42,27 +42,30 @@ def main():
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev)
         r = torch.randn(M, N, device=dev) if resid else None
-        bufs[name] = (a, w, b, out, r)
+        bufs[name] = (a, w, b, out, r, ops.pack_weight(w))
     for rd in range(rounds + 1):
         for name, M, K, N, act, resid, cnt, kv in SHAPES:
-            a, w, b, out, r = bufs[name]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops.gemm(a, w, bias=b, act=act, resid=r, out=out)
-            e1.record()
-            e1.synchronize()
-            if rd > 0:
-                res.setdefault(name, []).append(e0.elapsed_time(e1))
-    tot_t = tot_f = 0.0
-    print(f"{'shape':10s} {'M':>8s} {'K':>6s} {'N':>6s} {'ms(med)':>9s} {'TF/s':>8s} {'x/iter':>6s}")
-    for name, M, K, N, act, resid, cnt, kv in SHAPES:
-        ts = sorted(res[name])
-        med = ts[len(ts) // 2]
-        fl = 2.0 * M * N * kv
-        print(f"{name:10s} {M:8d} {K:6d} {N:6d} {med:9.3f} {fl / med / 1e9:8.1f} {cnt:6d}")
-        tot_t += med * cnt
-        tot_f += fl * cnt
-    print(f"aggregate per iteration: {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.1f} TF/s")
+            a, w, b, out, r, wp = bufs[name]
+            for mode, packed in (("f32", None), ("f16x3", wp)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.gemm(a, w, bias=b, act=act, resid=r, out=out, packed=packed)
+                e1.record()
+                e1.synchronize()
+                if rd > 0:
+                    res.setdefault((name, mode), []).append(e0.elapsed_time(e1))
+    for mode in ("f32", "f16x3"):
+        tot_t = tot_f = 0.0
+        print(f"--- back end {mode} (TF/s = algorithmic f32-equivalent flops / time)")
+        print(f"{'shape':10s} {'M':>8s} {'K':>6s} {'N':>6s} {'ms(med)':>9s} {'TF/s':>8s} {'x/iter':>6s}")
+        for name, M, K, N, act, resid, cnt, kv in SHAPES:
+            ts = sorted(res[(name, mode)])
+            med = ts[len(ts) // 2]
+            fl = 2.0 * M * N * kv
+            print(f"{name:10s} {M:8d} {K:6d} {N:6d} {med:9.3f} {fl / med / 1e9:8.1f} {cnt:6d}")
+            tot_t += med * cnt
+            tot_f += fl * cnt
+        print(f"aggregate per iteration: {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.1f} TF/s")
 
 
 if __name__ == "__main__":
