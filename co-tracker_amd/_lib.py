@@ -62,7 +62,7 @@ class GemmArgs(C.Structure):
         ("resid", _fp), ("ldr", C.c_int64),
         ("act", C.c_int32),
         ("batch", C.c_int32), ("a_bs", C.c_int64), ("c_bs", C.c_int64),
-        ("k_valid", C.c_int32),
+        ("k_valid", C.c_int32), ("a_split", C.c_int32), ("c_split", C.c_int32),
     ]
 
 
@@ -72,7 +72,7 @@ class AttnArgs(C.Structure):
         ("k", _fp), ("v", _fp), ("kv_ld", C.c_int64), ("kv_bs", C.c_int64), ("kv_is", C.c_int64),
         ("out", _fp), ("o_ld", C.c_int64), ("o_bs", C.c_int64), ("o_is", C.c_int64),
         ("nbatch", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
-        ("splits", C.c_int32), ("partial", _fp),
+        ("splits", C.c_int32), ("partial", _fp), ("o_split", C.c_int32),
     ]
 
 
@@ -91,7 +91,7 @@ SYMBOLS = {
     "ctk_corr_embed_workspace_bytes": (C.c_int, [_P(WindowArgs), _P(C.c_size_t)]),
     "ctk_corr_embed": (C.c_int, [_P(WindowArgs), _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
     "ctk_corr_volume": (C.c_int, [_P(WindowArgs), _fp, _fp]),
-    "ctk_assemble_tokens": (C.c_int, [_P(WindowArgs), _fp, _fp]),
+    "ctk_assemble_tokens": (C.c_int, [_P(WindowArgs), _fp, C.c_int32, _fp]),
     "ctk_update_former_workspace_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
     "ctk_update_former": (C.c_int, [C.c_int32, C.c_int32, _fp, _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
     "ctk_tap_indices": (C.c_int, [_P(WindowArgs), _fp, _fp]),
@@ -102,7 +102,8 @@ SYMBOLS = {
     "ctk_gemm": (C.c_int, [_P(GemmArgs), _fp]),
     "ctk_pack_weight_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
     "ctk_pack_weight": (C.c_int, [_fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp]),
-    "ctk_layernorm": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, C.c_float, _fp]),
+    "ctk_layernorm": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, C.c_float, C.c_int32, _fp]),
+    "ctk_split_rows": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp]),
     "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
     "ctk_profile_enable": (C.c_int, [C.c_int]),
     "ctk_profile_read": (C.c_int, [_P(ProfileRow), C.c_int, _P(C.c_int)]),

@@ -24,15 +24,22 @@ struct WRef {
   const void* p;
 };
 
+// lda / ldc / a_bs / c_bs are given in f32 ELEMENTS of the logical matrix; an SH operand stores two halves
+// per element, so its strides double (a row of K columns = 2K halves).
 int gemm(const float* A, long lda, int M, WRef W, long ldw, int N, int K, float* C, long ldc, const float* bias,
          int act, const float* resid, long ldr, hipStream_t s, const float* bias_rows = nullptr, int period = 0,
-         int batch = 1, long a_bs = 0, long c_bs = 0, int k_valid = 0) {
+         int batch = 1, long a_bs = 0, long c_bs = 0, int k_valid = 0, bool a_split = false, bool c_split = false) {
   ctk_gemm_args g;
   g.A = A; g.lda = lda; g.M = M; g.W = W.w; g.Wp = W.p; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
   g.bias = bias; g.bias_rows = bias_rows; g.bias_period = period; g.resid = resid; g.ldr = ldr; g.act = act;
   g.batch = batch; g.a_bs = a_bs; g.c_bs = c_bs; g.k_valid = k_valid;
+  g.a_split = a_split; g.c_split = c_split;
+  if (a_split) { g.lda *= 2; g.a_bs *= 2; }
+  if (c_split) { g.ldc *= 2; g.c_bs *= 2; }
   return ctk_gemm(&g, s);
 }
+
+bool split_mode(const ctk_model_weights* w) { return w->in_p != nullptr; }
 
 // ---- update-former workspace carve -------------------------------------------------------
 struct UfWs {
@@ -74,23 +81,26 @@ UfWs carve_uf(int S, int N, void* base) {
 
 int attn(const float* q, long q_ld, long q_bs, long q_is, const float* k, const float* v, long kv_ld, long kv_bs,
          long kv_is, float* out, long o_bs, long o_is, int nbatch, int n1, int n2, int splits, float* partial,
-         hipStream_t s) {
+         hipStream_t s, bool o_split) {
   ctk_attn_args a;
   a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.q_is = q_is;
   a.k = k; a.v = v; a.kv_ld = kv_ld; a.kv_bs = kv_bs; a.kv_is = kv_is;
-  a.out = out; a.o_ld = CTK_HID; a.o_bs = o_bs; a.o_is = o_is;
+  a.out = out; a.o_ld = o_split ? 2 * CTK_HID : CTK_HID; a.o_bs = o_bs; a.o_is = o_is; a.o_split = o_split;
   a.nbatch = nbatch; a.n1 = n1; a.n2 = n2; a.splits = splits; a.partial = partial;
   return ctk_attention(&a, s);
 }
 
 // residual MLP: x += fc2(gelu_tanh(fc1(LN(x))))  on rows [r0, r0+R)   (blocks.py:437 / cotracker.py:576)
-int mlp_block(const UfWs& ws, long r0, long R, const ctk_block_weights& b, hipStream_t s) {
+// In split mode (sp) the GEMM inputs xn / att / hid live in SH format (same bytes, same row offsets).
+int mlp_block(const UfWs& ws, long r0, long R, const ctk_block_weights& b, hipStream_t s, bool sp) {
   float* tok = ws.tokens + r0 * CTK_HID;
   float* xn = ws.xn + r0 * CTK_HID;
   float* hid = ws.hid + r0 * CTK_MLP;
-  CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, s));
-  CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.w1, b.w1_p}, CTK_HID, CTK_MLP, CTK_HID, hid, CTK_MLP, b.b1, CTK_ACT_GELU_TANH, nullptr, 0, s));
-  CTK_TRY(gemm(hid, CTK_MLP, (int)R, WRef{b.w2, b.w2_p}, CTK_MLP, CTK_HID, CTK_MLP, tok, CTK_HID, b.b2, CTK_ACT_NONE, tok, CTK_HID, s));
+  CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, sp, s));
+  CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.w1, b.w1_p}, CTK_HID, CTK_MLP, CTK_HID, hid, CTK_MLP, b.b1, CTK_ACT_GELU_TANH, nullptr, 0, s,
+               nullptr, 0, 1, 0, 0, 0, sp, sp));
+  CTK_TRY(gemm(hid, CTK_MLP, (int)R, WRef{b.w2, b.w2_p}, CTK_MLP, CTK_HID, CTK_MLP, tok, CTK_HID, b.b2, CTK_ACT_NONE, tok, CTK_HID, s,
+               nullptr, 0, 1, 0, 0, 0, sp, false));
   return CTK_OK;
 }
 
@@ -104,6 +114,7 @@ int check_block(const ctk_block_weights& b, bool cross) {
 // EfficientUpdateFormer.forward (cotracker.py:483-531) on tokens already holding the input
 // projection in rows [0, N*S).
 int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
+  const bool sp = split_mode(w);  // xn / att / hid are SH-format in split mode
   const long P = (long)N * S;             // point rows
   const long V = (long)CTK_VIRT * S;      // virtual rows
   const long R = P + V;
@@ -118,49 +129,49 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
     // ---- time attention over S for every track (incl. virtual)      cotracker.py:494-497
     {
       const ctk_block_weights& b = w->time_blocks[i];
-      CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, s));
-      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(attn(qkv, QL, S, 1, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, S, 1, att, S, 1, N + CTK_VIRT, S, S, 1, nullptr, s));
-      CTK_TRY(gemm(att, CTK_HID, (int)R, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
-      CTK_TRY(mlp_block(ws, 0, R, b, s));
+      CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, sp, s));
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(attn(qkv, QL, S, 1, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, S, 1, att, S, 1, N + CTK_VIRT, S, S, 1, nullptr, s, sp));
+      CTK_TRY(gemm(att, CTK_HID, (int)R, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(mlp_block(ws, 0, R, b, s, sp));
     }
     // ---- virtual <- points cross attention                          cotracker.py:510-512
     {
       const ctk_block_weights& b = w->virtual2point[i];
-      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, s));   // norm1(virtual)
-      CTK_TRY(ctk_layernorm(tok, xn, P, b.ctx_gamma, b.ctx_beta, 1e-5f, s));                        // norm_context(points)
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, sp, s));   // norm1(virtual)
+      CTK_TRY(ctk_layernorm(tok, xn, P, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));                        // norm_context(points)
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       // batch = frame t; query i = virtual track (row P + i*S + t); key j = point (row j*S + t)
       CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S, CTK_VIRT, N,
-                   v2p_splits(N), ws.partial, s));
+                   v2p_splits(N), ws.partial, s, sp));
       CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
-                   tok + P * CTK_HID, CTK_HID, s));
-      CTK_TRY(mlp_block(ws, P, V, b, s));
+                   tok + P * CTK_HID, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(mlp_block(ws, P, V, b, s, sp));
     }
     // ---- virtual self attention (AttnBlock over 64 virtual tracks per frame)  cotracker.py:514
     {
       const ctk_block_weights& b = w->virtual_self[i];
-      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, s));
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
+      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, sp, s));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S,
-                   CTK_VIRT, CTK_VIRT, 1, nullptr, s));
+                   CTK_VIRT, CTK_VIRT, 1, nullptr, s, sp));
       CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
-                   tok + P * CTK_HID, CTK_HID, s));
-      CTK_TRY(mlp_block(ws, P, V, b, s));
+                   tok + P * CTK_HID, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(mlp_block(ws, P, V, b, s, sp));
     }
     // ---- points <- virtual cross attention                          cotracker.py:515-517
     {
       const ctk_block_weights& b = w->point2virtual[i];
-      CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, s));                                              // norm1(points)
-      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, s));           // norm_context(virtual)
-      CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s));
-      CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s));
-      CTK_TRY(gemm(att, CTK_HID, (int)P, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s));
-      CTK_TRY(mlp_block(ws, 0, P, b, s));
+      CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, sp, s));                                              // norm1(points)
+      CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));           // norm_context(virtual)
+      CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s, sp));
+      CTK_TRY(gemm(att, CTK_HID, (int)P, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(mlp_block(ws, 0, P, b, s, sp));
     }
   }
   return CTK_OK;
@@ -169,6 +180,11 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
 int check_weights(const ctk_model_weights* w) {
   if (!w) return CTK_E_NULL;
   if ((!w->in_w && !w->in_p) || !w->in_bias_t || !w->virtual_tokens || !w->head_w || !w->head_b) return CTK_E_NULL;
+  const bool sp = split_mode(w);  // packed blobs are all-or-nothing: the SH activation pipeline needs every Linear split
+  auto bad = [sp](const ctk_block_weights& b) { return sp != (b.wq_p && b.wkv_p && b.wo_p && b.w1_p && b.w2_p) || (!sp && (b.wq_p || b.wkv_p || b.wo_p || b.w1_p || b.w2_p)); };
+  if (sp != (w->corr_fc1_p && w->corr_fc2_p)) return CTK_E_NULL;
+  for (int i = 0; i < CTK_DEPTH; ++i)
+    if (bad(w->time_blocks[i]) || bad(w->virtual2point[i]) || bad(w->virtual_self[i]) || bad(w->point2virtual[i])) return CTK_E_NULL;
   for (int i = 0; i < CTK_DEPTH; ++i) {
     CTK_TRY(check_block(w->time_blocks[i], false));
     CTK_TRY(check_block(w->virtual2point[i], true));
@@ -178,10 +194,10 @@ int check_weights(const ctk_model_weights* w) {
   return CTK_OK;
 }
 
-int input_projection(int S, int N, const float* x, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
+int input_projection(int S, int N, const float* x, bool x_split, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
   // tokens = input_transform(x + time_emb)   (cotracker3_online.py:247, cotracker.py:484)
   return gemm(x, CTK_X_LD, N * S, WRef{w->in_w, w->in_p}, CTK_X_LD, CTK_HID, CTK_X_LD, ws.tokens, CTK_HID, nullptr, CTK_ACT_NONE, nullptr, 0,
-              s, w->in_bias_t, S, 1, 0, 0, CTK_X_DIM);
+              s, w->in_bias_t, S, 1, 0, 0, CTK_X_DIM, x_split, false);
 }
 
 // ---- corr_embed workspace -------------------------------------------------------------------
@@ -212,7 +228,11 @@ CorrWs carve_corr(const ctk_window_args* a, void* base) {
   return w;
 }
 
-int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* x, const CorrWs& ws, hipStream_t s) {
+// x is f32 [N*S, CTK_X_LD] or, when x_split, the same matrix in SH format.  In split mode the hidden h1 is SH
+// (fc1's epilogue writes it, fc2 streams it); the correlation volume itself is still f32 (split while staged).
+int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* x, bool x_split, const CorrWs& ws, hipStream_t s) {
+  const bool sp = split_mode(w);
+  if (x_split && !sp) return CTK_E_SHAPE;
   if ((!w->corr_fc1_w && !w->corr_fc1_p) || !w->corr_fc1_b || (!w->corr_fc2_w && !w->corr_fc2_p) || !w->corr_fc2_b) return CTK_E_NULL;
   for (int n0 = 0; n0 < a->N; n0 += ws.chunk) {
     const int cnt = (a->N - n0 < ws.chunk) ? a->N - n0 : ws.chunk;
@@ -220,10 +240,10 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
     CTK_TRY(ctk_launch_corr_volume(a, n0, cnt, ws.vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
     // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
     CTK_TRY(gemm(ws.vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), WRef{w->corr_fc1_w, w->corr_fc1_p}, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, ws.h1, CTK_HID,
-                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s, nullptr, 0, 1, 0, 0, CTK_CORR_K));
+                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s, nullptr, 0, 1, 0, 0, CTK_CORR_K, false, sp));
     // corr_mlp.fc2, one batch per level, written into x[n*S+t][l*256 ...]   (torch.cat :209)
     CTK_TRY(gemm(ws.h1, CTK_HID, (int)rows, WRef{w->corr_fc2_w, w->corr_fc2_p}, CTK_HID, 256, CTK_HID, x + (long)n0 * a->S * CTK_X_LD + CTK_X_CORR,
-                 CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256));
+                 CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256, 0, sp, x_split));
   }
   return CTK_OK;
 }
@@ -266,7 +286,7 @@ extern "C" int ctk_update_former(int32_t S, int32_t N, const float* x, const ctk
   const UfWs ws = carve_uf(S, N, workspace);
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  CTK_TRY(input_projection(S, N, x, w, ws, s));
+  CTK_TRY(input_projection(S, N, x, false, w, ws, s));
   CTK_TRY(run_transformer(S, N, w, ws, s));
   return ctk_launch_heads(ws.tokens, w->head_w, w->head_b, S, N, delta, nullptr, nullptr, nullptr, s);
 }
@@ -285,7 +305,7 @@ extern "C" int ctk_corr_embed(const ctk_window_args* a, const ctk_model_weights*
   if (!ctk_aligned16(workspace) || !ctk_aligned16(x)) return CTK_E_ALIGN;
   const CorrWs ws = carve_corr(a, workspace);
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
-  return run_corr_embed(a, w, x, ws, static_cast<hipStream_t>(stream));
+  return run_corr_embed(a, w, x, false, ws, static_cast<hipStream_t>(stream));
 }
 
 // Workspace of a whole window: x | update-former buffers | correlation buffers
@@ -315,10 +335,11 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
   off += uws.bytes;
   const CorrWs cws = carve_corr(a, base + off);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool sp = split_mode(w);  // split mode: the transformer input x is kept in SH format
   for (int it = 0; it < a->iters; ++it) {                       // cotracker3_online.py:187
-    CTK_TRY(run_corr_embed(a, w, x, cws, s));                   // :190-210
-    CTK_TRY(ctk_assemble_tokens(a, x, s));                      // :212-245
-    CTK_TRY(input_projection(a->S, a->N, x, w, uws, s));        // :247 + cotracker.py:484
+    CTK_TRY(run_corr_embed(a, w, x, sp, cws, s));               // :190-210
+    CTK_TRY(ctk_assemble_tokens(a, x, sp, s));                  // :212-245
+    CTK_TRY(input_projection(a->S, a->N, x, sp, w, uws, s));    // :247 + cotracker.py:484
     CTK_TRY(run_transformer(a->S, a->N, w, uws, s));            // :250
     CTK_TRY(ctk_launch_heads(uws.tokens, w->head_w, w->head_b, a->S, a->N, nullptr, a->coords, a->vis, a->conf, s));  // :252-259
   }

@@ -14,6 +14,7 @@
 // permute+contiguous copies (cotracker.py:494,504,520).
 #include "ctk_common.h"
 #include "ctk_profile.h"
+#include "gemm_params.h"
 
 namespace {
 
@@ -29,6 +30,7 @@ struct AttnP {
   int nbatch, n1, n2;
   int splits, keys_per_split;
   float* partial;
+  int o_split; // out is SH halves (o_ld = halves per row)
   int bpw;     // batches per wave (n1 < 64) or 1
   int qtiles;  // ceil(n1/64) when n1 >= 64
   float scale;
@@ -134,10 +136,19 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnP p) {
   if (p.splits == 1) {
     const float inv = 1.0f / l;
     float* op = p.out + (myb * p.o_bs + myq * p.o_is) * p.o_ld + head * HD;
+    _Float16* oh = reinterpret_cast<_Float16*>(p.out) + (myb * p.o_bs + myq * p.o_is) * p.o_ld;
 #pragma unroll
     for (int d = 0; d < HD; d += 4) {
       f32x4 t = {acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
-      *reinterpret_cast<f32x4*>(op + d) = t;
+      if (p.o_split) {
+        f16x4 hi, lo;
+        ctk_split4(t, hi, lo);
+        _Float16* dst = oh + ctk_sh_col(head * HD + d);
+        *reinterpret_cast<f16x4*>(dst) = hi;
+        *reinterpret_cast<f16x4*>(dst + 32) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(op + d) = t;
+      }
     }
   } else {
     float* pp = p.partial + ((((long)split * p.nbatch + myb) * CTK_HEADS + head) * p.n1 + myq) * (HD + 2);
@@ -168,7 +179,15 @@ __global__ void attention_merge_kernel(AttnP p) {
     l += w * base[s * stride + 1];
     a += w * base[s * stride + 2 + d];
   }
-  p.out[(b * p.o_bs + qi * p.o_is) * p.o_ld + head * HD + d] = a / l;
+  const float o = a / l;
+  if (p.o_split) {
+    _Float16* oh = reinterpret_cast<_Float16*>(p.out) + (b * p.o_bs + qi * p.o_is) * p.o_ld + ctk_sh_col(head * HD + d);
+    const _Float16 hi = (_Float16)o;
+    oh[0] = hi;
+    oh[32] = (_Float16)(o - (float)hi);
+  } else {
+    p.out[(b * p.o_bs + qi * p.o_is) * p.o_ld + head * HD + d] = o;
+  }
 }
 
 }  // namespace
@@ -181,7 +200,9 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
   AttnP p;
   p.q = a->q; p.q_ld = a->q_ld; p.q_bs = a->q_bs; p.q_is = a->q_is;
   p.k = a->k; p.v = a->v; p.kv_ld = a->kv_ld; p.kv_bs = a->kv_bs; p.kv_is = a->kv_is;
-  p.out = a->out; p.o_ld = a->o_ld; p.o_bs = a->o_bs; p.o_is = a->o_is;
+  p.out = static_cast<float*>(a->out); p.o_ld = a->o_ld; p.o_bs = a->o_bs; p.o_is = a->o_is;
+  p.o_split = a->o_split;
+  if (p.o_split && (a->o_ld % 64)) return CTK_E_ALIGN;
   p.nbatch = a->nbatch; p.n1 = a->n1; p.n2 = a->n2;
   p.splits = a->splits > 1 ? a->splits : 1;
   if (p.splits > 1 && !a->partial) return CTK_E_NULL;

@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(CtkGemmP g) {
   const int mb = tile % g.mblocks;
   const int bz = tile / g.mblocks;
 
-  const float* A = g.A + (long)bz * g.a_bs;
-  float* C = g.C + (long)bz * g.c_bs;
+  const float* A = static_cast<const float*>(g.A) + (long)bz * g.a_bs;
+  float* C = static_cast<float*>(g.C) + (long)bz * g.c_bs;
   const int m0 = mb * BM, n0 = nb * BN;
 
   const int tid = threadIdx.x;
@@ -178,6 +178,10 @@ extern "C" int ctk_gemm(const ctk_gemm_args* a, void* stream) {
   g.bias = a->bias; g.bias_rows = a->bias_rows; g.bias_period = a->bias_period;
   g.resid = a->resid; g.ldr = a->ldr; g.act = a->act;
   g.batch = batch; g.a_bs = a->a_bs; g.c_bs = a->c_bs;
+  g.a_split = a->a_split; g.c_split = a->c_split;
+  if ((g.a_split || g.c_split) && !g.Wp) return CTK_E_SHAPE;  // SH operands exist only on the split-half back end
+  if (g.c_split && (g.resid || (a->ldc % 64))) return CTK_E_SHAPE;
+  if (g.a_split && (a->lda % 64)) return CTK_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const double kv = (double)(a->k_valid > 0 ? a->k_valid : a->K);
   const double flops = 2.0 * a->M * (double)a->N * kv * batch;

@@ -23,11 +23,7 @@
 #include "ctk_common.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
-
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+#include <cstdlib>
 
 namespace {
 
@@ -35,11 +31,66 @@ constexpr int BK = 32;
 constexpr int PITCH = BK + 8;      // halves per LDS row (80 bytes)
 constexpr int HDR_BYTES = 64;      // packed blob header: float s, float 1/s
 
-// x = hi + lo, both IEEE half, round-to-nearest-even.
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
-  hi = __builtin_convertvector(v, f16x4);
-  const f32x4 r = v - __builtin_convertvector(hi, f32x4);  // exact in f32
-  lo = __builtin_convertvector(r, f16x4);
+// ---- shared epilogue -------------------------------------------------------------------------
+// The swapped-operand 32x32 accumulator holds D'[n][m]: lane = output row m = lane & 31, register quad q
+// = output columns 8q + 4*(lane>>5) + 0..3.  v = act(acc/s + bias + bias_rows) + resid, written either as
+// f32 (float4 per quad) or in SH form (4 hi halves + 4 lo halves per quad: feeds the next GEMM's DMA).
+template <int MR, int NR>
+__device__ __forceinline__ void gemm_epilogue(const CtkGemmP& g, f32x16 (&acc)[MR][NR], const int m_base,
+                                              const int n_base, const int r32, const int half, const int bz) {
+  const float unscale = reinterpret_cast<const float*>(g.Wp)[1];
+  const bool has_res = g.resid != nullptr;
+  const float* Rz = has_res ? g.resid + (long)bz * g.c_bs : nullptr;
+  f32x4 res[MR][NR][4];
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi) {
+    const int row = min(m_base + mi * 32 + r32, g.M - 1);
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n_base + ni * 32 + q * 8 + half * 4;
+        res[mi][ni][q] = has_res ? *reinterpret_cast<const f32x4*>(Rz + (long)row * g.ldr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
+  float* Cf = static_cast<float*>(g.C) + (long)bz * g.c_bs;
+  _Float16* Ch = static_cast<_Float16*>(g.C) + (long)bz * g.c_bs;
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi) {
+    const int row = m_base + mi * 32 + r32;
+    const float* brow = g.bias_rows ? g.bias_rows + (long)(min(row, g.M - 1) % g.bias_period) * g.N : nullptr;
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n_base + ni * 32 + q * 8 + half * 4;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][q * 4 + e] * unscale;
+        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+        if (brow) v += *reinterpret_cast<const f32x4*>(brow + col);
+        if (g.act == CTK_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_erf(v[e]);
+        } else if (g.act == CTK_ACT_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_tanh(v[e]);
+        }
+        v += res[mi][ni][q];
+        if (row < g.M) {
+          if (g.c_split) {
+            f16x4 hi, lo;
+            ctk_split4(v, hi, lo);
+            _Float16* dst = Ch + (long)row * g.ldc + ctk_sh_col(col);
+            *reinterpret_cast<f16x4*>(dst) = hi;
+            *reinterpret_cast<f16x4*>(dst + 32) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(Cf + (long)row * g.ldc + col) = v;
+          }
+        }
+      }
+    }
+  }
 }
 
 template <int MR, int NR>
@@ -57,8 +108,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(CtkGemmP g) {
   const int mb = tile % g.mblocks;
   const int bz = tile / g.mblocks;
 
-  const float* A = g.A + (long)bz * g.a_bs;
-  float* C = g.C + (long)bz * g.c_bs;
+  const float* A = static_cast<const float*>(g.A) + (long)bz * g.a_bs;
   const int m0 = mb * BM, n0 = nb * BN;
   const int KT = g.K / BK;
 
@@ -102,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(CtkGemmP g) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       f16x4 hi, lo;
-      split4(sa[i], hi, lo);
+      ctk_split4(sa[i], hi, lo);
       *reinterpret_cast<f16x4*>(st + A_HI + (lr + 32 * i) * PITCH + c8 * 4) = hi;
       *reinterpret_cast<f16x4*>(st + A_LO + (lr + 32 * i) * PITCH + c8 * 4) = lo;
     }
@@ -155,48 +205,157 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(CtkGemmP g) {
     __syncthreads();
   }
 
-  // epilogue (layout as gemm.hip): m = lane & 31, n = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float unscale = reinterpret_cast<const float*>(g.Wp)[1];
-  const bool has_res = g.resid != nullptr;
-  const float* Rz = has_res ? g.resid + (long)bz * g.c_bs : nullptr;
-  f32x4 res[MR][NR][4];
+  gemm_epilogue<MR, NR>(g, acc, m0 + wm * 32 * MR, n0 + wn * 32 * NR, r32, half, bz);
+}
+
+// ---- SH-operand kernel: A already split (SH format), both operands straight to LDS by DMA ------------
+// Block = WM x WN waves, each wave MR x NR tiles of 32x32; K-tile = 32 columns = ONE 128-byte line per
+// row per operand (hi 64 B | lo 64 B).  global_load_lds_dwordx4 writes 1 KiB = 8 rows per wave
+// instruction, lane-linear, so the LDS image is unpadded [row][128 B]; bank conflicts are avoided by an
+// XOR swizzle of the 16-byte chunk index applied on the SOURCE address (lane (row, pos) fetches chunk
+// pos ^ ((row >> 1) & 7)) and undone in the fragment reads: the 16 lanes of a ds_read_b128 group then
+// cover 16 distinct 16-byte bank groups.  No staging registers, no conversion, no ds_write.
+template <int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+  constexpr int GROUPS = (BM + BN) / 8;   // 8-row DMA groups per K-tile (A rows then W rows)
+  constexpr int GPW = GROUPS / NW;        // groups per wave
+  static_assert(GROUPS % NW == 0, "DMA groups must divide evenly over the waves");
+  constexpr int STAGE = (BM + BN) * 128;  // bytes
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const unsigned nblk = gridDim.x;
+  unsigned tile = ctk_xcd_remap(blockIdx.x, nblk);
+  const int nb = tile % g.nblocks;
+  tile /= g.nblocks;
+  const int mb = tile % g.mblocks;
+  const int bz = tile / g.mblocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+  const int KT = g.K / BK;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  // DMA source pointers: group gi = i * NW + wave covers tile rows [8 gi, 8 gi + 8)
+  const _Float16* Ash = static_cast<const _Float16*>(g.A) + (long)bz * g.a_bs;
+  const _Float16* Wsh = reinterpret_cast<const _Float16*>(g.Wp) + HDR_BYTES / 2;
+  const _Float16* src[GPW];
 #pragma unroll
-  for (int mi = 0; mi < MR; ++mi) {
-    const int row = min(m0 + wm * 32 * MR + mi * 32 + r32, g.M - 1);
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = n0 + wn * 32 * NR + ni * 32 + q * 8 + half * 4;
-        res[mi][ni][q] = has_res ? *reinterpret_cast<const f32x4*>(Rz + (long)row * g.ldr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-  }
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi) {
-    const int row = m0 + wm * 32 * MR + mi * 32 + r32;
-    const float* brow = g.bias_rows ? g.bias_rows + (long)(min(row, g.M - 1) % g.bias_period) * g.N : nullptr;
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = n0 + wn * 32 * NR + ni * 32 + q * 8 + half * 4;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][q * 4 + e] * unscale;
-        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
-        if (brow) v += *reinterpret_cast<const f32x4*>(brow + col);
-        if (g.act == CTK_ACT_GELU_ERF) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_erf(v[e]);
-        } else if (g.act == CTK_ACT_GELU_TANH) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_tanh(v[e]);
-        }
-        v += res[mi][ni][q];
-        if (row < g.M) *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = v;
-      }
+  for (int i = 0; i < GPW; ++i) {
+    const int lrow = (i * NW + wave) * 8 + (lane >> 3);          // row inside the stage image
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);            // source chunk for this LDS position
+    if (lrow < BM) {
+      const int row = min(m0 + lrow, g.M - 1);                   // clamp: rows >= M are never stored
+      src[i] = Ash + (long)row * g.lda + chunk * 8;
+    } else {
+      src[i] = Wsh + (long)(n0 + lrow - BM) * KT * 64 + chunk * 8;
     }
   }
+  auto dma = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < GPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)kt * 64),
+                                       (__attribute__((address_space(3))) void*)(lds + stage * STAGE + (i * NW + wave) * 1024),
+                                       16, 0, 0);
+  };
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // fragment addressing: row r, data chunk c = plane*4 + j*2 + half lives at r*128 + ((c ^ f(r)) << 4), f(r) = (r>>1)&7;
+  // f depends on r32 only (the wave/tile row offsets are multiples of 32)
+  const int fsw = (r32 >> 1) & 7;
+  const int a_row = (wm * MR * 32 + r32) * 128;
+  const int w_row = (BM + wn * NR * 32 + r32) * 128;
+  int coff[2][2];  // [j][plane]
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) coff[j][p] = ((p * 4 + j * 2 + half) ^ fsw) << 4;
+
+  struct Frags {
+    f16x8 ah[MR], al[MR], wh[NR], wl[NR];
+  };
+  auto load_frags = [&](int stage, int j, Frags& f) {
+    const unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      f.ah[i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 4096 + coff[j][0]);
+      f.al[i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 4096 + coff[j][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      f.wh[i] = *reinterpret_cast<const f16x8*>(st + w_row + i * 4096 + coff[j][0]);
+      f.wl[i] = *reinterpret_cast<const f16x8*>(st + w_row + i * 4096 + coff[j][1]);
+    }
+  };
+  // operands swapped on purpose (see gemm.hip): D'[n][m], lane = output row m, register quad = 4 columns n.
+  // Small terms first; the same accumulator is revisited every MR*NR MFMAs.
+  auto mma_term = [&](const Frags& f, int term) {  // term 0: wl*ah, 1: wh*al, 2: wh*ah
+#pragma unroll
+    for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? f.wl[ni] : f.wh[ni], term == 1 ? f.al[mi] : f.ah[mi],
+                                                             acc[mi][ni], 0, 0, 0);
+  };
+
+  // Software pipeline (2 LDS stages, 2 fragment register sets): the fragments of k-step 1 are read from LDS while
+  // the MFMAs of k-step 0 run, and those of the NEXT tile's k-step 0 while this tile's k-step 1 runs, so an MFMA
+  // phase never waits on LDS latency.  The barrier in the middle of the tile releases its stage: all waves have
+  // finished reading it (lgkmcnt(0) is part of __syncthreads) and their DMA of tile kt+1 has landed (vmcnt(0));
+  // the DMA of tile kt+2 then has a whole tile of MFMAs to land before it is waited for.
+  Frags fa, fb;
+  dma(0, 0);
+  if (KT > 1) dma(1, 1);
+  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");  // tile 0 only
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  load_frags(0, 0, fa);
+  // (the last tile is peeled so that no control-flow merge sits between a set's loads and the other set's MFMAs:
+  //  at a merge hipcc falls back to lgkmcnt(0) and would expose the latency of the loads just issued)
+  for (int kt = 0; kt + 1 < KT; ++kt) {
+    const int st = kt & 1;
+    // The LDS reads of the other register set are issued AFTER the first MFMA group of this one: hipcc waits
+    // lgkmcnt(0) before a set's first use, so at that point only loads issued a half-tile ago may be in flight.
+    mma_term(fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(st, 1, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_term(fa, 1);
+    mma_term(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // vmcnt(0): my DMA of tile kt+1 landed; lgkmcnt(0): my reads of stage st are done
+    if (kt + 2 < KT) dma(kt + 2, st);
+    load_frags(st ^ 1, 0, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_term(fb, 0);
+    mma_term(fb, 1);
+    mma_term(fb, 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    const int st = (KT - 1) & 1;
+    mma_term(fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(st, 1, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_term(fa, 1);
+    mma_term(fa, 2);
+    mma_term(fb, 0);
+    mma_term(fb, 1);
+    mma_term(fb, 2);
+  }
+
+  gemm_epilogue<MR, NR>(g, acc, m0 + wm * 32 * MR, n0 + wn * 32 * NR, r32, half, bz);
 }
 
 // ---- weight packing ------------------------------------------------------------------------
@@ -229,7 +388,7 @@ __global__ void weight_pack_kernel(const float* W, long ldw, int N, int K, const
   f32x4 v = *reinterpret_cast<const f32x4*>(W + (long)n * ldw + k);
   v *= s;
   f16x4 hi, lo;
-  split4(v, hi, lo);
+  ctk_split4(v, hi, lo);
   _Float16* dst = reinterpret_cast<_Float16*>(out) + HDR_BYTES / 2 + ((long)n * (K / BK) + k / BK) * 64 + (k % BK);
   *reinterpret_cast<f16x4*>(dst) = hi;
   *reinterpret_cast<f16x4*>(dst + 32) = lo;
@@ -237,18 +396,78 @@ __global__ void weight_pack_kernel(const float* W, long ldw, int N, int K, const
 
 }  // namespace
 
+namespace {
+// Dev knob (read once): CTK_GEMM_TILE = 0 auto (128x128, 2 blocks/CU) | 2 force 256x128 (8 waves, 1 block/CU).
+int gemm_tile_pref() {
+  static const int v = [] {
+    const char* e = getenv("CTK_GEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+template <typename K>
+int launch_with_lds(K kernel, unsigned blocks, unsigned threads, size_t lds_bytes, const CtkGemmP& g, hipStream_t s) {
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, s, g);
+  (void)lds_bytes;
+  return CTK_OK;
+}
+}  // namespace
+
 int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
-  const long big_blocks = (long)((g.M + 127) / 128) * (g.N / 128) * g.batch;
-  if ((g.N % 128) == 0 && big_blocks >= 384) {
+  const long blocks128 = (long)((g.M + 127) / 128) * (g.N / 128) * g.batch;
+  const bool big = (g.N % 128) == 0 && blocks128 >= 384;
+  if (g.a_split) {
+    const int pref = gemm_tile_pref();
+    if (big && pref == 2) {
+      g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 128;
+      CtkProfScope ps("gemm_sh_256x128", flops, bytes, s);
+      hipLaunchKernelGGL((gemm_sh_kernel<4, 2, 2, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(512), 0, s, g);
+    } else if (big) {
+      g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;
+      CtkProfScope ps("gemm_sh_128x128", flops, bytes, s);
+      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2>), dim3((unsigned)blocks128), dim3(256), 0, s, g);
+    } else {
+      g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
+      CtkProfScope ps("gemm_sh_64x64", flops, bytes, s);
+      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
+    }
+  } else if (big) {
     g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;
     CtkProfScope ps("gemm_f16x3_128x128", flops, bytes, s);
-    hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2>), dim3((unsigned)big_blocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2>), dim3((unsigned)blocks128), dim3(256), 0, s, g);
   } else {
     g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
     const long blocks = (long)g.mblocks * g.nblocks * g.batch;
     CtkProfScope ps("gemm_f16x3_64x64", flops, bytes, s);
     hipLaunchKernelGGL((gemm_f16x3_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   }
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}
+
+// f32 [M][K] (row stride ld) -> SH [M][K/32][2][32]
+namespace {
+__global__ void split_rows_kernel(const float* x, long ld, long M, int K, _Float16* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4
+  const int K4 = K / 4;
+  if (i >= M * K4) return;
+  const long m = i / K4;
+  const int k = (int)(i % K4) * 4;
+  f16x4 hi, lo;
+  ctk_split4(*reinterpret_cast<const f32x4*>(x + m * ld + k), hi, lo);
+  _Float16* dst = out + m * (long)(K / 32) * 64 + ctk_sh_col(k);
+  *reinterpret_cast<f16x4*>(dst) = hi;
+  *reinterpret_cast<f16x4*>(dst + 32) = lo;
+}
+}  // namespace
+
+extern "C" int ctk_split_rows(const float* x, int64_t ld, int64_t M, int32_t K, void* out, void* stream) {
+  if (!x || !out) return CTK_E_NULL;
+  if (M <= 0 || K <= 0 || (K % 32)) return CTK_E_SHAPE;
+  if ((ld % 4) || !ctk_aligned16(x) || !ctk_aligned16(out)) return CTK_E_ALIGN;
+  const long total = M * (K / 4);
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     (long)ld, (long)M, K, static_cast<_Float16*>(out));
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }

@@ -2,6 +2,7 @@
 // broadcast and the output heads fused with the (coords, vis, conf) state update.
 #include "ctk_common.h"
 #include "ctk_profile.h"
+#include "gemm_params.h"
 
 namespace {
 
@@ -9,7 +10,7 @@ namespace {
 // nn.LayerNorm(384, elementwise_affine=False, eps=1e-6)  blocks.py:411,416 / cotracker.py:539,549
 // nn.LayerNorm(384) (affine, eps=1e-5)                    cotracker.py:540 (norm_context)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y, long R, const float* gamma,
-                                                         const float* beta, float eps) {
+                                                         const float* beta, float eps, int out_split) {
   const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= R) return;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y
   const float var = ctk_wave_sum(q) * (1.0f / CTK_HID);
   const float rstd = 1.0f / sqrtf(var + eps);
   float* yr = y + row * CTK_HID;
+  _Float16* yh = reinterpret_cast<_Float16*>(y) + row * (2 * CTK_HID);  // SH row: 12 tiles x 64 halves
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int c = j * 128 + lane * 2;
@@ -39,7 +41,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y
       o.x = o.x * gamma[c] + beta[c];
       o.y = o.y * gamma[c + 1] + beta[c + 1];
     }
-    *reinterpret_cast<float2*>(yr + c) = o;
+    if (out_split) {
+      f16x2 hi, lo;
+      ctk_split2(f32x2{o.x, o.y}, hi, lo);
+      *reinterpret_cast<f16x2*>(yh + ctk_sh_col(c)) = hi;
+      *reinterpret_cast<f16x2*>(yh + ctk_sh_col(c) + 32) = lo;
+    } else {
+      *reinterpret_cast<float2*>(yr + c) = o;
+    }
   }
 }
 
@@ -47,7 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y
 // cotracker3_online.py:212-245 and posenc :19-39.  The time embedding (:247) is folded into the
 // input projection's per-frame bias (ctk_model_weights.in_bias_t).
 __global__ void assemble_kernel(const float* coords, const float* vis, const float* conf, int S, int N, float scale_x,
-                                float scale_y, float* x) {
+                                float scale_y, float* x, int x_split) {
   constexpr int EW = CTK_X_LD - CTK_X_VIS;  // 96 columns written per row
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)S * N * EW;
@@ -85,7 +94,14 @@ __global__ void assemble_kernel(const float* coords, const float* vis, const flo
       out = sinf(a);
     }
   }
-  x[row * CTK_X_LD + CTK_X_VIS + e] = out;
+  if (x_split) {  // SH row: 35 tiles x 64 halves
+    _Float16* xh = reinterpret_cast<_Float16*>(x) + row * (2 * CTK_X_LD) + ctk_sh_col(CTK_X_VIS + e);
+    const _Float16 hi = (_Float16)out;
+    xh[0] = hi;
+    xh[32] = (_Float16)(out - (float)hi);
+  } else {
+    x[row * CTK_X_LD + CTK_X_VIS + e] = out;
+  }
 }
 
 // ---- virtual tokens: tokens[(N+v)*S + t] = virual_tracks[v]   (cotracker.py:487-488) --------
@@ -138,25 +154,26 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* tokens, const f
 
 }  // namespace
 
-extern "C" int ctk_layernorm(const float* x, float* y, int64_t R, const float* gamma, const float* beta, float eps,
-                             void* stream) {
+extern "C" int ctk_layernorm(const float* x, void* y, int64_t R, const float* gamma, const float* beta, float eps,
+                             int32_t out_split, void* stream) {
   if (!x || !y) return CTK_E_NULL;
   if (R <= 0) return CTK_E_SHAPE;
   if ((gamma == nullptr) != (beta == nullptr)) return CTK_E_NULL;
   CtkProfScope ps("layernorm", 8.0 * R * CTK_HID, 8.0 * R * CTK_HID, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     y, (long)R, gamma, beta, eps);
+                     static_cast<float*>(y), (long)R, gamma, beta, eps, out_split);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }
 
-extern "C" int ctk_assemble_tokens(const ctk_window_args* a, float* x, void* stream) {
+extern "C" int ctk_assemble_tokens(const ctk_window_args* a, void* x, int32_t x_split, void* stream) {
   if (!a || !a->coords || !a->vis || !a->conf || !x) return CTK_E_NULL;
   if (a->S <= 0 || a->N <= 0 || !(a->scale_x > 0.f) || !(a->scale_y > 0.f)) return CTK_E_SHAPE;
   const long total = (long)a->S * a->N * (CTK_X_LD - CTK_X_VIS);
   CtkProfScope ps("assemble_tokens", 0.0, 4.0 * total, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a->coords, a->vis, a->conf, a->S, a->N, a->scale_x, a->scale_y, x);
+                     static_cast<hipStream_t>(stream), a->coords, a->vis, a->conf, a->S, a->N, a->scale_x, a->scale_y,
+                     static_cast<float*>(x), x_split);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }

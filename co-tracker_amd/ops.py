@@ -45,22 +45,34 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, act: int = L.ACT_NONE, resid=None, bias_rows=None,
-         out: Optional[torch.Tensor] = None, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, packed: Optional[torch.Tensor] = None, out_split: bool = False) -> torch.Tensor:
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + bias_rows[m % period]) + resid.
-    packed = pack_weight(w) selects the split-half (3 x f16 MFMA) back end; None the exact-f32 one."""
-    _chk_f32(a, w, bias, bias_rows)
+    packed = pack_weight(w) selects the split-half (3 x f16 MFMA) back end; None the exact-f32 one.
+    With the split-half back end, a may be an SH tensor [M,K/32,2,32] float16 (split_rows) and out_split
+    returns the result in SH form."""
+    a_split = a.dtype == torch.float16
+    if a_split:
+        assert packed is not None and a.is_cuda and a.is_contiguous() and a.dim() == 4
+        _chk_f32(w, bias, bias_rows)
+        M, K = a.shape[0], a.shape[1] * 32
+    else:
+        _chk_f32(a, w, bias, bias_rows)
+        M, K = a.shape
     for t_ in (resid, out):  # row-strided views are fine (leading dimension is passed explicitly)
         if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.stride(1) == 1):
             raise ValueError("out/resid must be float32 device tensors with unit column stride")
-    M, K = a.shape
     N = w.shape[0]
-    if out is None:
+    if out_split:
+        assert packed is not None and resid is None and out is None
+        out = torch.empty(M, N // 32, 2, 32, device=a.device, dtype=torch.float16)
+    elif out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     g = L.GemmArgs()
-    g.A, g.lda, g.M = _ptr(a), K, M
+    g.A, g.lda, g.M = _ptr(a), (2 * K if a_split else K), M
+    g.a_split, g.c_split = int(a_split), int(out_split)
     g.W, g.ldw, g.N, g.K = _ptr(w), w.shape[1], N, K
     g.Wp = _ptr(packed)
-    g.C, g.ldc = _ptr(out), out.stride(0)
+    g.C, g.ldc = _ptr(out), (2 * N if out_split else out.stride(0))
     g.bias = _ptr(bias)
     g.bias_rows = _ptr(bias_rows)
     g.bias_period = bias_rows.shape[0] if bias_rows is not None else 0
@@ -71,25 +83,43 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, act: int = L.ACT_NONE, res
     return out
 
 
-def layernorm(x: torch.Tensor, gamma=None, beta=None, eps: float = 1e-6) -> torch.Tensor:
+def split_rows(x: torch.Tensor) -> torch.Tensor:
+    """f32 [M,K] (K % 32 == 0) -> SH format: float16 tensor [M, K/32, 2, 32] (hi plane, lo plane), x = hi + lo."""
+    _chk_f32(x)
+    M, K = x.shape
+    out = torch.empty(M, K // 32, 2, 32, device=x.device, dtype=torch.float16)
+    L.check(L.load().ctk_split_rows(_ptr(x), K, M, K, _ptr(out), _stream()), "ctk_split_rows")
+    return out
+
+
+def unsplit(sh: torch.Tensor) -> torch.Tensor:
+    """SH tensor [M, K/32, 2, 32] float16 -> f32 [M,K] (test helper: hi + lo)."""
+    M, KT = sh.shape[0], sh.shape[1]
+    return (sh[:, :, 0].float() + sh[:, :, 1].float()).reshape(M, KT * 32)
+
+
+def layernorm(x: torch.Tensor, gamma=None, beta=None, eps: float = 1e-6, out_split: bool = False) -> torch.Tensor:
     _chk_f32(x, gamma, beta)
     assert x.shape[-1] == L.HID
-    y = torch.empty_like(x)
-    L.check(L.load().ctk_layernorm(_ptr(x), _ptr(y), x.numel() // L.HID, _ptr(gamma), _ptr(beta), float(eps), _stream()),
+    R = x.numel() // L.HID
+    y = torch.empty(R, L.HID // 32, 2, 32, device=x.device, dtype=torch.float16) if out_split else torch.empty_like(x)
+    L.check(L.load().ctk_layernorm(_ptr(x), _ptr(y), R, _ptr(gamma), _ptr(beta), float(eps), int(out_split), _stream()),
             "ctk_layernorm")
     return y
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, splits: int = 1) -> torch.Tensor:
-    """q [B,N1,384], k/v [B,N2,384] (8 heads x 48, heads contiguous in the last dim) -> [B,N1,384]."""
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, splits: int = 1, out_split: bool = False) -> torch.Tensor:
+    """q [B,N1,384], k/v [B,N2,384] (8 heads x 48, heads contiguous in the last dim) -> [B,N1,384]
+    (or its SH form [B*N1, 12, 2, 32] float16 when out_split)."""
     _chk_f32(q, k, v)
     B, N1, _ = q.shape
     N2 = k.shape[1]
-    out = torch.empty_like(q)
+    out = torch.empty(B * N1, L.HID // 32, 2, 32, device=q.device, dtype=torch.float16) if out_split else torch.empty_like(q)
     a = L.AttnArgs()
     a.q, a.q_ld, a.q_bs, a.q_is = _ptr(q), L.HID, N1, 1
     a.k, a.v, a.kv_ld, a.kv_bs, a.kv_is = _ptr(k), _ptr(v), L.HID, N2, 1
-    a.out, a.o_ld, a.o_bs, a.o_is = _ptr(out), L.HID, N1, 1
+    a.out, a.o_ld, a.o_bs, a.o_is = _ptr(out), (2 * L.HID if out_split else L.HID), N1, 1
+    a.o_split = int(out_split)
     a.nbatch, a.n1, a.n2 = B, N1, N2
     a.splits = splits
     part = None
@@ -225,7 +255,7 @@ def corr_embed(win: Window, weights, x: Optional[torch.Tensor] = None) -> torch.
 
 
 def assemble_tokens(win: Window, x: torch.Tensor) -> torch.Tensor:
-    L.check(L.load().ctk_assemble_tokens(C.byref(win.args), _ptr(x), _stream()), "ctk_assemble_tokens")
+    L.check(L.load().ctk_assemble_tokens(C.byref(win.args), _ptr(x), 0, _stream()), "ctk_assemble_tokens")
     return x
 
 

@@ -141,7 +141,8 @@ int ctk_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
 int ctk_corr_volume(const ctk_window_args* a, float* out, void* stream);
 
 /* ---- Op C: assemble_tokens (cotracker3_online.py:212-245, posenc :19-39) -> x[:,1024:1120] */
-int ctk_assemble_tokens(const ctk_window_args* a, float* x, void* stream);
+int ctk_assemble_tokens(const ctk_window_args* a, void* x /* f32 [N*S,CTK_X_LD], or SH when x_split */,
+                        int32_t x_split, void* stream);
 
 /* ---- Op B: EfficientUpdateFormer.forward (cotracker.py:483-531): x -> delta [N*S,4] */
 int ctk_update_former_workspace_bytes(int32_t S, int32_t N, size_t* out_bytes);
@@ -185,27 +186,37 @@ typedef struct ctk_gemm_args {
   int32_t act;
   int32_t batch; int64_t a_bs; int64_t c_bs;
   int32_t k_valid;         /* non-padding columns of K (0 = K); only used for flop accounting */
+  int32_t a_split;         /* A is in SH format (see below): lda / a_bs count halves, lda % 64 == 0; needs Wp */
+  int32_t c_split;         /* write C in SH format: ldc / c_bs count halves, ldc % 64 == 0, no resid; needs Wp */
 } ctk_gemm_args;
 int ctk_gemm(const ctk_gemm_args* g, void* stream);
 /* Split a torch-layout weight [N,K] (K % 32 == 0, row stride ldw) into the packed two-half form
  * the split-half back end reads: 64-byte header {s, 1/s} (s = power of two, chosen on the device
  * from max|W|) + [N][K/32][2][32] IEEE halves (hi, lo of s*W).  Done once per weight at load.   */
+/* SH ("split-half") format of an activation matrix X[M][K], K % 32 == 0: IEEE halves
+ * [M][K/32][2][32] -- per row and 32-column tile one 128-byte line: 32 hi halves, 32 lo halves,
+ * x = hi + lo (hi = rn16(x), lo = rn16(x - hi), |x| < 65504).  Same size as f32.  The split-half
+ * GEMM streams it straight into LDS; LayerNorm / attention / GEMM epilogues / token assembly can
+ * emit it.  ctk_split_rows converts f32 [M][K] (row stride ld floats) to SH.                      */
+int ctk_split_rows(const float* x, int64_t ld, int64_t M, int32_t K, void* out, void* stream);
 int ctk_pack_weight_bytes(int32_t N, int32_t K, size_t* out_bytes);
 int ctk_pack_weight(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream);
 
-/* LayerNorm over 384 channels, rows [0,R): y = (x-mean)/sqrt(var+eps) [*gamma+beta].  */
-int ctk_layernorm(const float* x, float* y, int64_t R, const float* gamma, const float* beta,
-                  float eps, void* stream);
+/* LayerNorm over 384 channels, rows [0,R): y = (x-mean)/sqrt(var+eps) [*gamma+beta].
+ * y is f32 [R,384], or SH [R][12][2][32] halves when out_split != 0.                     */
+int ctk_layernorm(const float* x, void* y, int64_t R, const float* gamma, const float* beta,
+                  float eps, int32_t out_split, void* stream);
 
 /* softmax(q k^T * 48^-0.5) v  (Attention.forward, blocks.py:379-398), 8 heads x 48.
  * row(b,i) = b*bs + i*is (rows of a matrix with leading dimension ld floats).           */
 typedef struct ctk_attn_args {
   const float* q; int64_t q_ld; int64_t q_bs; int64_t q_is;
   const float* k; const float* v; int64_t kv_ld; int64_t kv_bs; int64_t kv_is;
-  float* out; int64_t o_ld; int64_t o_bs; int64_t o_is;
+  void* out; int64_t o_ld; int64_t o_bs; int64_t o_is;   /* f32, or SH halves (o_ld = 768) when o_split */
   int32_t nbatch; int32_t n1; int32_t n2;
   int32_t splits;          /* key-range splits (>1 needs workspace) */
   float* partial;          /* [splits, nbatch, 8, n1, 50] or NULL    */
+  int32_t o_split;         /* write out in SH format                 */
 } ctk_attn_args;
 int ctk_attention(const ctk_attn_args* a, void* stream);
 

@@ -114,6 +114,16 @@ def test_gemm(M, K, N, act, precision):
     # transposition-detecting: plain product with asymmetric operands and no epilogue
     out2 = ops.gemm(a, w, packed=wp)
     assert maxdiff(out2, a.double() @ w.double().t()) < tol
+    if split:
+        # SH-format operands: A pre-split (direct-to-LDS kernel), C written in SH form
+        a_sh = ops.split_rows(a)
+        assert maxdiff(ops.unsplit(a_sh), a) < 2e-6
+        out3 = ops.gemm(a_sh, w, bias=bias, act=act, resid=resid, bias_rows=brows, packed=wp)
+        assert maxdiff(out3, ref) < tol
+        assert maxdiff(ops.gemm(a_sh, w, packed=wp), a.double() @ w.double().t()) < tol
+        for src in (a, a_sh):
+            out4 = ops.gemm(src, w, bias=bias, act=act, bias_rows=brows, packed=wp, out_split=True)
+            assert maxdiff(ops.unsplit(out4), ref - resid.double()) < tol
 
 
 @pytest.mark.parametrize("wscale", [1e-6, 1e-3, 1.0, 3e4])
@@ -150,6 +160,19 @@ def test_gemm_inplace_residual_and_strided_out():
     assert maxdiff(tok, ref) < 2e-5
 
 
+def test_gemm_sh_k_range_and_batch():
+    """SH GEMM on a column window of a wider SH matrix and batched over column blocks (the corr_mlp.fc2 -> x pattern)."""
+    from cotracker_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M = 700
+    h = torch.randn(4, M, 384, generator=g).to(dev())          # 4 "levels"
+    w = (torch.randn(256, 384, generator=g) / 20).to(dev())
+    wp = ops.pack_weight(w)
+    for lvl in range(4):
+        out = ops.gemm(ops.split_rows(h[lvl].contiguous()), w, packed=wp, out_split=True)
+        assert maxdiff(ops.unsplit(out), h[lvl].double() @ w.double().t()) < 2e-5
+
+
 @pytest.mark.parametrize("affine", [False, True])
 def test_layernorm(affine):
     from cotracker_amd import ops
@@ -162,6 +185,8 @@ def test_layernorm(affine):
     ref = torch.nn.functional.layer_norm(x.double(), (384,), gamma.double() if affine else None,
                                          beta.double() if affine else None, eps)
     assert maxdiff(y, ref) < 5e-6
+    ysh = ops.layernorm(x, gamma if affine else None, beta if affine else None, eps, out_split=True)
+    assert maxdiff(ops.unsplit(ysh), ref) < 8e-6  # SH output: hi + lo carries >= 21 significant bits
 
 
 @pytest.mark.parametrize("B,N1,N2,splits", [(37, 16, 16, 1), (5, 120, 120, 1), (16, 64, 700, 4), (3, 200, 64, 1),
@@ -178,6 +203,8 @@ def test_attention(B, N1, N2, splits):
     vh = v.double().reshape(B, N2, 8, 48).transpose(1, 2)
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 48 ** -0.5, -1) @ vh).transpose(1, 2).reshape(B, N1, 384)
     assert maxdiff(out, ref) < 5e-6
+    osh = ops.attention(q, k, v, splits=splits, out_split=True)
+    assert maxdiff(ops.unsplit(osh).reshape(B, N1, 384), ref) < 8e-6
 
 
 # ------------------------------------------------------------------------------------------

@@ -31,6 +31,11 @@ SHAPES = [  # name, M, K, N, act, resid, count per iteration, k_valid
 ]
 
 
+MODES = os.environ.get("MODES", "f32,f16x3,sh,sh2sh").split(",")
+if os.environ.get("SHAPES"):
+    SHAPES = [s_ for s_ in SHAPES if s_[0] in os.environ["SHAPES"].split(",")]
+
+
 def main():
     dev = torch.device("cuda:0")
     rounds = int(os.environ.get("ROUNDS", "5"))
@@ -42,21 +47,28 @@ def main():
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev)
         r = torch.randn(M, N, device=dev) if resid else None
-        bufs[name] = (a, w, b, out, r, ops.pack_weight(w))
+        bufs[name] = (a, w, b, out, r, ops.pack_weight(w), ops.split_rows(a))
     for rd in range(rounds + 1):
         for name, M, K, N, act, resid, cnt, kv in SHAPES:
-            a, w, b, out, r, wp = bufs[name]
-            for mode, packed in (("f32", None), ("f16x3", wp)):
+            a, w, b, out, r, wp, ash = bufs[name]
+            for mode in MODES:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.gemm(a, w, bias=b, act=act, resid=r, out=out, packed=packed)
+                if mode == "f32":
+                    ops.gemm(a, w, bias=b, act=act, resid=r, out=out)
+                elif mode == "f16x3":
+                    ops.gemm(a, w, bias=b, act=act, resid=r, out=out, packed=wp)
+                elif mode == "sh":
+                    ops.gemm(ash, w, bias=b, act=act, resid=r, out=out, packed=wp)
+                else:  # sh2sh: SH in, SH out (no residual)
+                    ops.gemm(ash, w, bias=b, act=act, packed=wp, out_split=True)
                 e1.record()
                 e1.synchronize()
                 if rd > 0:
                     res.setdefault((name, mode), []).append(e0.elapsed_time(e1))
-    for mode in ("f32", "f16x3"):
+    for mode in MODES:
         tot_t = tot_f = 0.0
-        print(f"--- back end {mode} (TF/s = algorithmic f32-equivalent flops / time)")
+        print(f"--- back end {mode}, CTK_GEMM_TILE={os.environ.get('CTK_GEMM_TILE', '0')} (TF/s = algorithmic f32-equivalent flops / time)")
         print(f"{'shape':10s} {'M':>8s} {'K':>6s} {'N':>6s} {'ms(med)':>9s} {'TF/s':>8s} {'x/iter':>6s}")
         for name, M, K, N, act, resid, cnt, kv in SHAPES:
             ts = sorted(res[(name, mode)])
