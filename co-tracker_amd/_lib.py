@@ -91,6 +91,8 @@ SYMBOLS = {
     "ctk_corr_embed_workspace_bytes": (C.c_int, [_P(WindowArgs), _P(C.c_size_t)]),
     "ctk_corr_embed": (C.c_int, [_P(WindowArgs), _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
     "ctk_corr_volume": (C.c_int, [_P(WindowArgs), _fp, _fp]),
+    "ctk_corr_volume_sh_workspace_bytes": (C.c_int, [_P(WindowArgs), _P(C.c_size_t)]),
+    "ctk_corr_volume_sh": (C.c_int, [_P(WindowArgs), _fp, _fp, C.c_size_t, _fp]),
     "ctk_assemble_tokens": (C.c_int, [_P(WindowArgs), _fp, C.c_int32, _fp]),
     "ctk_update_former_workspace_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
     "ctk_update_former": (C.c_int, [C.c_int32, C.c_int32, _fp, _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),

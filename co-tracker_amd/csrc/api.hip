@@ -4,6 +4,9 @@
 
 int ctk_launch_corr_volume(const ctk_window_args* a, int n0, int ncount, float* out, long level_stride, int ld,
                            hipStream_t s);
+int ctk_launch_pyramid_split(const float* fmap, long pixels, void* out, hipStream_t s);
+int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh, int n0, int ncount, void* out,
+                              long level_stride_halves, hipStream_t s);
 int ctk_launch_virtual_init(const float* vt, int S, float* dst, hipStream_t s);
 int ctk_launch_heads(const float* tokens, const float* hw, const float* hb, int S, int N, float* delta, float* coords,
                      float* vis, float* conf, hipStream_t s);
@@ -202,8 +205,9 @@ int input_projection(int S, int N, const float* x, bool x_split, const ctk_model
 
 // ---- corr_embed workspace -------------------------------------------------------------------
 struct CorrWs {
-  float* vol;  // [4][chunk*S][2432]
-  float* h1;   // [4*chunk*S][384]
+  float* vol;  // [4][chunk*S][2432]   (SH format in split mode: same bytes)
+  float* h1;   // [4*chunk*S][384]     (SH format in split mode)
+  void* fm_sh[CTK_LEVELS];  // split mode: SH copy of the window's pyramid (scaled by 2^8), [S*H*W][4][2][32] halves
   size_t bytes;
   int chunk;
 };
@@ -224,12 +228,27 @@ CorrWs carve_corr(const ctk_window_args* a, void* base) {
   off += align256(rows * CTK_LEVELS * CTK_CORR_LD * sizeof(float));
   w.h1 = reinterpret_cast<float*>(p + off);
   off += align256(rows * CTK_LEVELS * CTK_HID * sizeof(float));
+  for (int l = 0; l < CTK_LEVELS; ++l) {  // always carved (the size query does not know the weights' mode): ~8 MB per frame
+    w.fm_sh[l] = p + off;
+    off += align256((size_t)a->S * (a->H[l] > 0 ? a->H[l] : 0) * (a->W[l] > 0 ? a->W[l] : 0) * CTK_C * sizeof(float));
+  }
   w.bytes = off;
   return w;
 }
 
+// split mode, once per window: SH copy of the pyramid for the correlation sampler's footprint DMA
+int prepare_pyramid_sh(const ctk_window_args* a, const CorrWs& ws, hipStream_t s) {
+  for (int l = 0; l < CTK_LEVELS; ++l) {
+    if (!a->fmaps[l]) return CTK_E_NULL;
+    if (a->H[l] <= 0 || a->W[l] <= 0) return CTK_E_SHAPE;
+    CTK_TRY(ctk_launch_pyramid_split(a->fmaps[l], (long)a->S * a->H[l] * a->W[l], ws.fm_sh[l], s));
+  }
+  return CTK_OK;
+}
+
 // x is f32 [N*S, CTK_X_LD] or, when x_split, the same matrix in SH format.  In split mode the hidden h1 is SH
-// (fc1's epilogue writes it, fc2 streams it); the correlation volume itself is still f32 (split while staged).
+// (fc1's epilogue writes it, fc2 streams it) and so is the correlation volume (corr_sh.hip); the caller has run
+// prepare_pyramid_sh for this window.
 int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* x, bool x_split, const CorrWs& ws, hipStream_t s) {
   const bool sp = split_mode(w);
   if (x_split && !sp) return CTK_E_SHAPE;
@@ -237,10 +256,11 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
   for (int n0 = 0; n0 < a->N; n0 += ws.chunk) {
     const int cnt = (a->N - n0 < ws.chunk) ? a->N - n0 : ws.chunk;
     const long rows = (long)cnt * a->S;
-    CTK_TRY(ctk_launch_corr_volume(a, n0, cnt, ws.vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
+    if (sp) CTK_TRY(ctk_launch_corr_volume_sh(a, ws.fm_sh, n0, cnt, ws.vol, rows * CTK_CORR_LD * 2, s));
+    else CTK_TRY(ctk_launch_corr_volume(a, n0, cnt, ws.vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
     // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
     CTK_TRY(gemm(ws.vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), WRef{w->corr_fc1_w, w->corr_fc1_p}, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, ws.h1, CTK_HID,
-                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s, nullptr, 0, 1, 0, 0, CTK_CORR_K, false, sp));
+                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s, nullptr, 0, 1, 0, 0, CTK_CORR_K, sp, sp));
     // corr_mlp.fc2, one batch per level, written into x[n*S+t][l*256 ...]   (torch.cat :209)
     CTK_TRY(gemm(ws.h1, CTK_HID, (int)rows, WRef{w->corr_fc2_w, w->corr_fc2_p}, CTK_HID, 256, CTK_HID, x + (long)n0 * a->S * CTK_X_LD + CTK_X_CORR,
                  CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256, 0, sp, x_split));
@@ -305,7 +325,23 @@ extern "C" int ctk_corr_embed(const ctk_window_args* a, const ctk_model_weights*
   if (!ctk_aligned16(workspace) || !ctk_aligned16(x)) return CTK_E_ALIGN;
   const CorrWs ws = carve_corr(a, workspace);
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
+  if (split_mode(w)) CTK_TRY(prepare_pyramid_sh(a, ws, static_cast<hipStream_t>(stream)));
   return run_corr_embed(a, w, x, false, ws, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ctk_corr_volume_sh_workspace_bytes(const ctk_window_args* a, size_t* out_bytes) {
+  return ctk_corr_embed_workspace_bytes(a, out_bytes);
+}
+
+extern "C" int ctk_corr_volume_sh(const ctk_window_args* a, void* out, void* workspace, size_t workspace_bytes, void* stream) {
+  CTK_TRY(check_window(a));
+  if (!out || !workspace) return CTK_E_NULL;
+  if (!ctk_aligned16(workspace) || !ctk_aligned16(out)) return CTK_E_ALIGN;
+  const CorrWs ws = carve_corr(a, workspace);
+  if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  CTK_TRY(prepare_pyramid_sh(a, ws, s));
+  return ctk_launch_corr_volume_sh(a, ws.fm_sh, 0, a->N, out, (long)a->N * a->S * CTK_CORR_LD * 2, s);
 }
 
 // Workspace of a whole window: x | update-former buffers | correlation buffers
@@ -336,6 +372,7 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
   const CorrWs cws = carve_corr(a, base + off);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool sp = split_mode(w);  // split mode: the transformer input x is kept in SH format
+  if (sp && a->iters > 0) CTK_TRY(prepare_pyramid_sh(a, cws, s));
   for (int it = 0; it < a->iters; ++it) {                       // cotracker3_online.py:187
     CTK_TRY(run_corr_embed(a, w, x, sp, cws, s));               // :190-210
     CTK_TRY(ctk_assemble_tokens(a, x, sp, s));                  // :212-245

@@ -242,6 +242,17 @@ def corr_volume(win: Window) -> torch.Tensor:
     return out
 
 
+def corr_volume_sh(win: Window) -> torch.Tensor:
+    """Split-half sampler: SH volumes [4, N*S, 76, 2, 32] float16 (use unsplit on a level to compare)."""
+    lib = L.load()
+    out = torch.empty(L.LEVELS, win.N * win.S, L.CORR_LD // 32, 2, 32, device=win.device, dtype=torch.float16)
+    nbytes = C.c_size_t(0)
+    L.check(lib.ctk_corr_volume_sh_workspace_bytes(C.byref(win.args), C.byref(nbytes)), "ctk_corr_volume_sh_workspace_bytes")
+    ws = _workspace(nbytes.value, win.device)
+    L.check(lib.ctk_corr_volume_sh(C.byref(win.args), _ptr(out), _ptr(ws), ws.numel(), _stream()), "ctk_corr_volume_sh")
+    return out
+
+
 def corr_embed(win: Window, weights, x: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()
     if x is None:

@@ -139,6 +139,11 @@ int ctk_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
 /* 49x49 correlation volume only (before corr_mlp), for parity tests:
  * out [4][N*S][CTK_CORR_LD], row = n*S+t.                                             */
 int ctk_corr_volume(const ctk_window_args* a, float* out, void* stream);
+/* The same volumes from the split-half pipeline's sampler (footprint x support on f16 MFMA x3, blend after
+ * the correlation), in SH format: out halves [4][N*S][2*CTK_CORR_LD].  workspace holds the SH copy of the
+ * window's pyramid (ctk_corr_volume_sh_workspace_bytes).                                                  */
+int ctk_corr_volume_sh_workspace_bytes(const ctk_window_args* a, size_t* out_bytes);
+int ctk_corr_volume_sh(const ctk_window_args* a, void* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Op C: assemble_tokens (cotracker3_online.py:212-245, posenc :19-39) -> x[:,1024:1120] */
 int ctk_assemble_tokens(const ctk_window_args* a, void* x /* f32 [N*S,CTK_X_LD], or SH when x_split */,

@@ -300,6 +300,56 @@ def test_corr_volume(golden, ops_model):
     assert maxdiff(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3]) == 0.0
 
 
+def test_corr_volume_sh(golden, ops_model):
+    """Split-half sampler (footprint correlation on f16 MFMA x3, blend afterwards) vs the reference goldens."""
+    from cotracker_amd import ops
+    g = golden("ops")
+    win = make_window(g, ops_model)
+    S, N = win.S, win.N
+    vol = ops.corr_volume_sh(win)  # SH [4, N*S, 76, 2, 32]
+    for l in range(4):
+        full = ops.unsplit(vol[l])
+        assert float(full[:, 2401:].abs().max()) == 0.0
+        if l in (0, 3):
+            ours = full[:, :2401].reshape(N, S, 2401).transpose(0, 1).cpu().numpy()
+            assert maxdiff(ours, g[f"corr_volume{l}"][0]) < 3e-6
+    mask = torch.ones(N, dtype=torch.uint8, device=dev())
+    mask[::3] = 0
+    vol2 = ops.corr_volume_sh(make_window(g, ops_model, mask=mask)).reshape(4, N, S, -1)
+    assert float(vol2[:, ::3].float().abs().max()) == 0.0
+    assert torch.equal(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3])
+
+
+@pytest.mark.parametrize("S", [5, 20])
+def test_corr_volume_sh_stress_coordinates(S):
+    """Integer / half-integer / border / out-of-range coordinates (9-wide footprints, clamped taps), ragged frame
+    chunks (S = 5: one short chunk; S = 20: 16 + 4) -- against the exact-f32 fused sampler (itself pinned to the goldens)."""
+    from cotracker_amd import ops
+    r = np.random.RandomState(S)
+    H0, W0, N = 48, 64, 90
+    f0 = torch.from_numpy(r.standard_normal((S, H0, W0, 128)).astype(np.float32)).to(dev())
+    f0 = (f0 / f0.norm(dim=-1, keepdim=True)).contiguous()
+    pyr = ops.build_pyramid(f0)
+    c = r.uniform(-6, 1, size=(S, N, 2)) * np.array([W0 + 10, H0 + 10]) * np.array([-1, -1]) * -1  # spans beyond both borders
+    c = r.uniform(-8, 8, size=(S, N, 2)) + r.uniform(0, 1, size=(S, N, 2)) * np.array([W0 - 1, H0 - 1])
+    c[:, 0:20] = np.round(c[:, 0:20])                 # integers: the round trip floors some of them to x-1
+    c[:, 20:30] = np.round(c[:, 20:30]) + 0.5
+    c[:, 30:40] = np.round(c[:, 30:40] / 8) * 8       # multiples of 8: integer at every pyramid level
+    c[:, 40] = [0.0, 0.0]
+    c[:, 41] = [W0 - 1, H0 - 1]
+    c[:, 42] = [-50.0, 1000.0]
+    c[:, 43] = [W0 + 2.25, -3.5]
+    coords = torch.from_numpy(c.astype(np.float32)).to(dev())
+    qc = coords[0].contiguous()
+    sup = [ops.sample_support(pyr[l], torch.zeros(N, device=dev()), (qc / 2 ** l).contiguous()) for l in range(4)]
+    vis, conf = torch.zeros(S, N, device=dev()), torch.zeros(S, N, device=dev())
+    win = ops.Window(pyr, sup, coords, vis, conf, (W0, H0), iters=1)
+    ref = ops.corr_volume(win)
+    got = ops.corr_volume_sh(win)
+    for l in range(4):
+        assert maxdiff(ops.unsplit(got[l]), ref[l]) < 3e-6
+
+
 def test_corr_embed(golden, ops_model):
     from cotracker_amd import ops
     g = golden("ops")
