@@ -19,7 +19,7 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -88,6 +88,10 @@ SYMBOLS = {
     "ctk_error_string": (C.c_char_p, [C.c_int]),
     "ctk_forward_window_workspace_bytes": (C.c_int, [_P(WindowArgs), _P(C.c_size_t)]),
     "ctk_forward_window": (C.c_int, [_P(WindowArgs), _P(ModelWeights), _fp, C.c_size_t, _fp]),
+    "ctk_window_graph_create": (C.c_int, [_P(WindowArgs), _P(ModelWeights), _fp, C.c_size_t, _P(C.c_void_p)]),
+    "ctk_window_graph_launch": (C.c_int, [C.c_void_p, _fp]),
+    "ctk_window_graph_nodes": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
+    "ctk_window_graph_destroy": (C.c_int, [C.c_void_p]),
     "ctk_corr_embed_workspace_bytes": (C.c_int, [_P(WindowArgs), _P(C.c_size_t)]),
     "ctk_corr_embed": (C.c_int, [_P(WindowArgs), _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
     "ctk_corr_volume": (C.c_int, [_P(WindowArgs), _fp, _fp]),

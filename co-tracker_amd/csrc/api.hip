@@ -1,6 +1,8 @@
 // C-ABI orchestration: one update iteration = corr_embed -> assemble_tokens -> update_former
 // -> heads + state update, all enqueued on the caller's stream (no host sync, capturable).
 #include "ctk_common.h"
+#include "ctk_profile.h"
+#include <new>
 
 int ctk_launch_corr_volume(const ctk_window_args* a, int n0, int ncount, float* out, long level_stride, int ld,
                            hipStream_t s);
@@ -286,6 +288,7 @@ extern "C" const char* ctk_error_string(int code) {
     case CTK_E_SHAPE: return "unsupported shape";
     case CTK_E_ALIGN: return "pointer or leading dimension not 16-byte aligned";
     case CTK_E_WORKSPACE: return "workspace too small";
+    case CTK_E_STATE: return "call not allowed in the current state";
     default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown error";
   }
 }
@@ -380,5 +383,80 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
     CTK_TRY(run_transformer(a->S, a->N, w, uws, s));            // :250
     CTK_TRY(ctk_launch_heads(uws.tokens, w->head_w, w->head_b, a->S, a->N, nullptr, a->coords, a->vis, a->conf, s));  // :252-259
   }
+  return CTK_OK;
+}
+
+// ---- hipGraph of one window (BASELINE.json configs[3]) ------------------------------------------------------
+struct ctk_window_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int64_t nodes;
+};
+
+extern "C" int ctk_window_graph_create(const ctk_window_args* a, const ctk_model_weights* w, void* workspace,
+                                       size_t workspace_bytes, ctk_window_graph** out) {
+  if (!out) return CTK_E_NULL;
+  *out = nullptr;
+  if (ctk_profile_is_on()) return CTK_E_STATE;
+  // validate before touching the capture machinery (ctk_forward_window repeats these checks)
+  CTK_TRY(check_window(a));
+  CTK_TRY(check_weights(w));
+  if (!workspace || !a->coords || !a->vis || !a->conf) return CTK_E_NULL;
+  size_t need = 0;
+  CTK_TRY(ctk_forward_window_workspace_bytes(a, &need));
+  if (need > workspace_bytes) return CTK_E_WORKSPACE;
+
+  hipStream_t cs = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  if (e != hipSuccess) return (int)e;
+  // thread-local mode: allocations made by other host threads (e.g. torch's caching allocator) stay legal
+  e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(cs);
+    return (int)e;
+  }
+  const int rc = ctk_forward_window(a, w, workspace, workspace_bytes, cs);
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(cs, &graph);
+  (void)hipStreamDestroy(cs);
+  if (rc != CTK_OK || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc != CTK_OK ? rc : (e != hipSuccess ? (int)e : (int)hipErrorUnknown);
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    return (int)e;
+  }
+  size_t n = 0;
+  (void)hipGraphGetNodes(graph, nullptr, &n);
+  ctk_window_graph* g = new (std::nothrow) ctk_window_graph{graph, exec, (int64_t)n};
+  if (!g) {
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    return (int)hipErrorOutOfMemory;
+  }
+  *out = g;
+  return CTK_OK;
+}
+
+extern "C" int ctk_window_graph_launch(ctk_window_graph* g, void* stream) {
+  if (!g) return CTK_E_NULL;
+  const hipError_t e = hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? CTK_OK : (int)e;
+}
+
+extern "C" int ctk_window_graph_nodes(const ctk_window_graph* g, int64_t* out_nodes) {
+  if (!g || !out_nodes) return CTK_E_NULL;
+  *out_nodes = g->nodes;
+  return CTK_OK;
+}
+
+extern "C" int ctk_window_graph_destroy(ctk_window_graph* g) {
+  if (!g) return CTK_OK;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
   return CTK_OK;
 }

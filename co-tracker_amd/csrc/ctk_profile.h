@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+bool ctk_profile_is_on();
+
 class CtkProfScope {
  public:
   CtkProfScope(const char* name, double flops, double bytes, hipStream_t s);

@@ -31,6 +31,8 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+bool ctk_profile_is_on() { return g_on; }
+
 CtkProfScope::CtkProfScope(const char* name, double flops, double bytes, hipStream_t s) : idx_(-1), s_(s) {
   if (!g_on) return;
   Rec r;

@@ -227,14 +227,19 @@ class CoTrackerThreeBase(nn.Module):
         # arithmetic of the Linear layers: "f16x3" = split-half MFMA (3 f16 MFMAs per product, f32 accumulate,
         # fp32-class accuracy at 5.3x the f32-MFMA ceiling), "f32" = exact-f32 MFMA.  Not a reference kwarg.
         self.precision = DEFAULT_PRECISION
+        # hipGraph replay of the streaming window (BASELINE.json configs[3]): with is_online=True the whole
+        # window (iters x ~190 launches) is captured once per (S, N, iters) and replayed with one graph launch
+        # per chunk.  Not a reference kwarg; CoTrackerOnlinePredictor switches it on.
+        self.hip_graph = False
+        self._graphs = {}
 
     # -- weights ------------------------------------------------------------------------
     def load_state_dict(self, *args, **kwargs):
-        self._packed = None
+        self.invalidate_packed_weights()
         return super().load_state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):
-        self._packed = None
+        self.invalidate_packed_weights()
         return super()._apply(fn, *args, **kwargs)
 
     def packed(self, device) -> PackedWeights:
@@ -245,6 +250,34 @@ class CoTrackerThreeBase(nn.Module):
     def invalidate_packed_weights(self):
         """Call after mutating parameters in place (e.g. weights.fill_synthetic_)."""
         self._packed = None
+        if getattr(self, "_graphs", None):
+            self._graphs = {}  # captured graphs hold pointers into the old packed weights
+
+    def _graphed_window(self, fm, support, coords, vis, conf, mask, iters, pw):
+        """Run one window through its captured hipGraph: static buffers are created (and the graph captured) on
+        first use of this (shapes, iters, weights) combination, then only refreshed in place and replayed.
+        Returns the static coords/vis/conf tensors (overwritten by the next call)."""
+        key = (tuple(tuple(f.shape) for f in fm), coords.shape[1], int(iters), id(pw), coords.device.index)
+        g = self._graphs.get(key)
+        if g is None:
+            st_fm = [f.clone() for f in fm]
+            st_sup = [s_.clone() for s_ in support]
+            win = ops.Window(st_fm, st_sup, coords.clone(), vis.clone(), conf.clone(), self._scale_xy(), iters=iters,
+                             point_mask=mask.clone(), max_corr_rows=self.max_corr_rows)
+            g = ops.WindowGraph(win, pw)
+            self._graphs = {key: g}  # one live graph per model: a new shape replaces the old one (frees its workspace)
+        else:
+            st_fm, st_sup, c_, v_, f_, m_ = g.win.keep
+            for d, s_ in zip(st_fm, fm):
+                d.copy_(s_)
+            for d, s_ in zip(st_sup, support):
+                d.copy_(s_)
+            c_.copy_(coords)
+            v_.copy_(vis)
+            f_.copy_(conf)
+            m_.copy_(mask)
+        g.launch()
+        return g.win.keep[2], g.win.keep[3], g.win.keep[4]
 
     # -- shared pieces ------------------------------------------------------------------
     def _scale_xy(self):
@@ -365,12 +398,15 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
                 conf_init = torch.where(copy_over, fprev, conf_init).contiguous()
             mask = (qframes < ind + S).to(torch.uint8).contiguous()  # attention_mask :484, used as :493-496
             fm = pyr if is_online else [p_[ind:ind + S] for p_ in pyr]
-            coords = coords_init.clone()
-            vis = vis_init.clone()
-            conf = conf_init.clone()
-            win = ops.Window(fm, support, coords, vis, conf, self._scale_xy(), iters=iters, point_mask=mask,
-                             max_corr_rows=self.max_corr_rows)
-            ops.forward_window(win, pw)
+            if is_online and self.hip_graph:
+                coords, vis, conf = self._graphed_window(fm, support, coords_init, vis_init, conf_init, mask, iters, pw)
+            else:
+                coords = coords_init.clone()
+                vis = vis_init.clone()
+                conf = conf_init.clone()
+                win = ops.Window(fm, support, coords, vis, conf, self._scale_xy(), iters=iters, point_mask=mask,
+                                 max_corr_rows=self.max_corr_rows)
+                ops.forward_window(win, pw)
             S_trim = T if is_online else min(T - ind, S)
             coords_pred[ind:ind + S] = (coords * float(self.stride))[:S_trim]
             vis_pred[ind:ind + S] = vis[:S_trim]

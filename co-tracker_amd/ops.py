@@ -236,6 +236,42 @@ def forward_window(win: Window, weights) -> None:
     L.check(lib.ctk_forward_window(C.byref(win.args), C.byref(mw), _ptr(ws), ws.numel(), _stream()), "ctk_forward_window")
 
 
+class WindowGraph:
+    """hipGraph of one whole window (all `iters` iterations, ~190 launches each) captured once by
+    ctk_window_graph_create and replayed with ONE graph launch per call (BASELINE.json configs[3]).
+
+    The graph bakes in the pointers of ``win``'s tensors, of the weights and of a private workspace, so the
+    caller refreshes the CONTENTS of win's tensors in place (``copy_``) and calls ``launch()``."""
+
+    def __init__(self, win: Window, weights):
+        lib = L.load()
+        nbytes = C.c_size_t(0)
+        L.check(lib.ctk_forward_window_workspace_bytes(C.byref(win.args), C.byref(nbytes)), "ctk_forward_window_workspace_bytes")
+        self.win = win
+        self.weights = weights                      # keeps every weight tensor (and in_bias_t for this S) alive
+        self.ws = torch.empty(nbytes.value, device=win.device, dtype=torch.uint8)  # private: its address is baked in
+        mw = weights.struct_for(win.S)
+        h = C.c_void_p()
+        torch.cuda.synchronize(win.device)          # weight packing / input copies issued so far are complete
+        L.check(lib.ctk_window_graph_create(C.byref(win.args), C.byref(mw), _ptr(self.ws), self.ws.numel(), C.byref(h)),
+                "ctk_window_graph_create")
+        self._h = h
+        n = C.c_int64(0)
+        L.check(lib.ctk_window_graph_nodes(self._h, C.byref(n)), "ctk_window_graph_nodes")
+        self.nodes = n.value
+
+    def launch(self) -> None:
+        L.check(L.load().ctk_window_graph_launch(self._h, _stream()), "ctk_window_graph_launch")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                L.load().ctk_window_graph_destroy(h)
+            except Exception:
+                pass
+
+
 def corr_volume(win: Window) -> torch.Tensor:
     out = torch.empty(L.LEVELS, win.N * win.S, L.CORR_LD, device=win.device, dtype=torch.float32)
     L.check(L.load().ctk_corr_volume(C.byref(win.args), _ptr(out), _stream()), "ctk_corr_volume")

@@ -143,6 +143,7 @@ class CoTrackerOnlinePredictor(torch.nn.Module):
         self.step = model.window_len // 2
         self.model = model
         self.model.eval()
+        self.model.hip_graph = True  # streaming: replay the captured window graph per chunk (configs[3])
 
     @torch.no_grad()
     def forward(self, video_chunk, is_first_step: bool = False, queries: torch.Tensor = None, grid_size: int = 5,

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 2
+#define CTK_ABI_VERSION 3
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -64,7 +64,8 @@ enum {
   CTK_E_NULL = -1,      /* required pointer is NULL            */
   CTK_E_SHAPE = -2,     /* size out of range / not supported   */
   CTK_E_ALIGN = -3,     /* pointer or leading dimension not 16-byte aligned */
-  CTK_E_WORKSPACE = -4  /* workspace too small                 */
+  CTK_E_WORKSPACE = -4, /* workspace too small                 */
+  CTK_E_STATE = -5      /* call not allowed in the current state (e.g. graph capture while the profiler is on) */
 };
 
 enum { CTK_ACT_NONE = 0, CTK_ACT_GELU_ERF = 1, CTK_ACT_GELU_TANH = 2 };
@@ -130,6 +131,21 @@ const char* ctk_error_string(int code);
 int ctk_forward_window_workspace_bytes(const ctk_window_args* a, size_t* out_bytes);
 int ctk_forward_window(const ctk_window_args* a, const ctk_model_weights* w,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- hipGraph of a whole window (BASELINE.json configs[3]: streaming update captured once, replayed per chunk)
+ * ctk_window_graph_create captures ONE ctk_forward_window(a, w, workspace) -- every launch of all `iters`
+ * iterations -- on a private capture stream and instantiates it.  The executable graph bakes in the POINTERS
+ * of *a, *w and workspace: the caller keeps those buffers alive and at the same addresses and refreshes their
+ * CONTENTS (pyramid, support, coords/vis/conf, point_mask) before every ctk_window_graph_launch, which
+ * enqueues the whole window on `stream` as one graph launch.  The handle is a host object owned by the caller
+ * (destroy with ctk_window_graph_destroy); it holds no device memory.  Capture is refused (CTK_E_STATE)
+ * while ctk_profile_enable(1) is active: events cannot be recorded inside a capture.                      */
+typedef struct ctk_window_graph ctk_window_graph;
+int ctk_window_graph_create(const ctk_window_args* a, const ctk_model_weights* w, void* workspace,
+                            size_t workspace_bytes, ctk_window_graph** out);
+int ctk_window_graph_launch(ctk_window_graph* g, void* stream);
+int ctk_window_graph_nodes(const ctk_window_graph* g, int64_t* out_nodes); /* kernel nodes captured */
+int ctk_window_graph_destroy(ctk_window_graph* g);
 
 /* ---- Op A: corr_embed  (cotracker3_online.py:190-210; get_correlation_feat :130-143,
  *      einsum :202-204, corr_mlp :205) -> x[:, 0:1024]                                */

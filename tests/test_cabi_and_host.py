@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SYMBOLS), f"binding/header mismatch: {declared ^ set(_lib.SYMBOLS)}"
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_argument_validation_without_gpu(lib):
@@ -52,6 +52,10 @@ def test_argument_validation_without_gpu(lib):
     a.S, a.N, a.iters = 16, 100, 6
     assert lib.ctk_forward_window_workspace_bytes(C.byref(a), C.byref(n)) == 0 and n.value > 0
     assert lib.ctk_forward_window(C.byref(a), None, None, 0, None) == -1
+    h = C.c_void_p()
+    assert lib.ctk_window_graph_create(C.byref(a), None, None, 0, C.byref(h)) == -1 and not h.value  # validated before capture
+    assert lib.ctk_window_graph_launch(None, None) == -1
+    assert lib.ctk_window_graph_destroy(None) == 0
 
 
 def test_struct_sizes_match_header():

@@ -471,6 +471,54 @@ def test_model_online_sliding_and_streaming(golden):
     assert maxdiff(cs, c) < 2e-4
 
 
+def test_window_graph_replay_is_bit_identical(golden, ops_model):
+    """hipGraph (BASELINE.json configs[3]): the captured window replays the same launches -> identical bits to the
+    direct ctk_forward_window call, also after the inputs were refreshed in place (second replay)."""
+    from cotracker_amd import ops
+    g = golden("ops")
+    pw = ops_model.packed(dev())
+    direct = []
+    for shift in (0.0, 0.75):
+        win = make_window(g, ops_model, coords=t(g["coords"][0]) + shift, iters=3)
+        ops.forward_window(win, pw)
+        direct.append([x.clone() for x in win.keep[2:5]])
+    win = make_window(g, ops_model, coords=t(g["coords"][0]), iters=3)
+    gr = ops.WindowGraph(win, pw)
+    assert gr.nodes > 100  # every launch of the 3 iterations is a node of ONE graph
+    gr.launch()
+    for a, b in zip(win.keep[2:5], direct[0]):
+        assert maxdiff(a, b) == 0.0
+    win.keep[2].copy_(t(g["coords"][0]) + 0.75)   # refresh state in place, replay
+    win.keep[3].zero_()
+    win.keep[4].zero_()
+    gr.launch()
+    for a, b in zip(win.keep[2:5], direct[1]):
+        assert maxdiff(a, b) == 0.0
+
+
+def test_model_online_streaming_hip_graph(golden):
+    """Streaming with hip_graph=True (what CoTrackerOnlinePredictor uses) == streaming without, == reference golden."""
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_online")
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=1)
+    m = m.to(dev())
+    video, q = t(g["on_video"]), t(g["on_queries"])
+    outs = {}
+    for use_graph in (False, True):
+        m.hip_graph = use_graph
+        m.init_video_online_processing()
+        for ind in range(0, video.shape[1] - 4, 4):
+            cs, vs, fs, _ = m(video[:, ind:ind + 8], q, iters=4, is_online=True)
+        outs[use_graph] = (cs.clone(), vs.clone(), fs.clone())
+    assert len(m._graphs) == 1
+    for a, b in zip(outs[False], outs[True]):
+        assert maxdiff(a, b) == 0.0
+    assert maxdiff(outs[True][0], g["on_stream_coords"]) < 1e-3
+    assert maxdiff(logit(outs[True][1]), logit(g["on_stream_vis"])) < 1e-4
+
+
 def test_model_offline(golden):
     from cotracker_amd.model import CoTrackerThreeOffline
     from cotracker_amd.weights import fill_synthetic_
