@@ -38,6 +38,8 @@ WORKLOADS = {
     "c3_sliding": (512, 512, 120, 80, False, 16, "512x512 T=120 N=6400 cotracker3 online-weights sliding window S=16 (BASELINE.json configs[2])"),
     "c3_offline": (512, 512, 120, 80, True, 60, "512x512 T=120 N=6400 cotracker3_offline single window S=120"),
     "c2_offline": (256, 256, 48, 20, True, 60, "256x256 T=48 N=400 cotracker3_offline (BASELINE.json configs[1])"),
+    "c4_online": (512, 512, 0, 32, False, 16, "512x512 cotracker3_online streaming, 16-frame chunks advancing 8, N=1024, "
+                  "window replayed as ONE hipGraph per chunk (BASELINE.json configs[3])"),
     "tiny": (128, 160, 24, 8, False, 8, "smoke-sized"),
 }
 
@@ -50,6 +52,9 @@ def parse():
     ap.add_argument("--workload", default="c3_sliding", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="c4_online: direct launches instead of the captured hipGraph")
+    ap.add_argument("--pmc-traffic", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                    help="per-kernel HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="Linear back end: split-half MFMA (3 f16 MFMAs per product, fp32-class accuracy) or exact-f32 MFMA")
     return ap.parse_args()
@@ -91,6 +96,43 @@ def cpu_baseline(window_len, overlap_factor, iters=6):
             "sample": f"numpy oracle, update path only (no encoder): 1 window S={S}, N={N}, 1 iteration "
                       f"({dt:.1f} s) on a 96x128 4-level pyramid; scaled by {iters} iters x {overlap_factor:.3f} window overlap",
             "host_logical_cpus": os.cpu_count()}
+
+
+def roofline_entry(row, traffic, force_hbm=False):
+    """Roofline object of one kernel row of the HIP-event recorder.  `achieved` = ALGORITHMIC work of the launches /
+    their summed HIP-event duration.  Split-half kernels (gemm_sh_* / gemm_f16x3_* / corr_volume_sh) form every
+    f32-class product from 3 f16 MFMAs, so their MFMA ceiling in algorithmic flops is 2500/3 = 833 TF/s."""
+    name = row["name"]
+    sec = row["total_ms"] * 1e-3
+    n = max(row["launches"], 1)
+    tr = traffic.get(name)
+    out = {"kernel": name, "launches": row["launches"], "avg_launch_us": round(1e6 * sec / n, 1)}
+    if force_hbm:
+        gbs = row["bytes"] / sec / 1e9
+        out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": row["bytes"] / n,
+                    "note": "algorithmic sampler bytes (SURVEY 8d: 8x8x128 footprint per (t,n,level) + support/S + volume out, "
+                            "no inter-point reuse assumed) / HIP-event time; neighbouring grid points share footprint pixels "
+                            "in L2, so measured HBM traffic is lower than the algorithmic figure"})
+    else:
+        ach = row["flops"] / sec / 1e12
+        split = name.startswith(("gemm_sh", "gemm_f16x3", "corr_volume_sh"))
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
+        out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "flops_per_launch": row["flops"] / n})
+        if split:
+            out.update({"mfma_issued": round(3 * ach, 1), "mfma_peak": F16_MFMA_PEAK_TFLOPS, "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
+                        "note": "achieved = algorithmic (f32-equivalent) flops / HIP-event time; every product is 3 "
+                                "v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, f32 accumulate), so peak = dense f16 MFMA "
+                                "2500 TF/s / 3; frac is also mfma_issued / mfma_peak.  The exact-f32 MFMA peak is 157.3 TF/s"})
+        else:
+            out["note"] = "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) peak"
+    if tr:
+        out["traffic"] = tr.get("hbm_bytes_per_launch")
+        out["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "dispatches", "source") if k in tr}
+    else:
+        out["traffic"] = None
+    return out
 
 
 def parity_probe(dev):
@@ -150,12 +192,31 @@ def main():
 
     H, W, T, G, offline, wl, desc = WORKLOADS[args.workload]
     N = G * G
-    pred = CoTrackerPredictor(checkpoint=None, offline=offline, window_len=wl)
+    streaming = args.workload == "c4_online"
+    if streaming:
+        from cotracker_amd.predictor import CoTrackerOnlinePredictor
+        pred = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
+        pred.model.hip_graph = not args.no_graph
+        T = pred.step * (args.steps + args.warmup + 3)  # one chunk call per step, plus the profiled call
+    else:
+        pred = CoTrackerPredictor(checkpoint=None, offline=offline, window_len=wl)
     fill_synthetic_(pred.model, seed=0)
     pred = pred.to(dev)
     video = synthetic_video(T, H, W, seed=1234).to(dev)  # resident in HBM before timing starts
 
-    if world == 1:
+    if streaming:
+        # CoTrackerOnlinePredictor protocol (predictor.py:228-300): first call registers the grid queries, then every
+        # call consumes the last 2*step frames; one bench step = one such call = `step` new frames for N points.
+        pred(video_chunk=video[:, :2 * pred.step], is_first_step=True, grid_size=G)
+        cursor = [0]
+        if world > 1:
+            raise SystemExit("c4_online is a single-GPU latency workload")
+
+        def step():
+            i = cursor[0]
+            cursor[0] += pred.step
+            return pred(video_chunk=video[:, i:i + 2 * pred.step])
+    elif world == 1:
         def step():
             return pred(video, grid_size=G)
     else:
@@ -189,7 +250,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     sec_per_step = float(tmax.item()) / args.steps
     assert torch.isfinite(out[0]).all()
-    value = world * N * T / sec_per_step
+    frames_per_step = pred.step if streaming else T
+    value = world * N * frames_per_step / sec_per_step
 
     result = {
         "metric": "tracked-point-frames/sec (N*T/s)", "value": round(value, 1), "unit": "tracked-point-frames/s",
@@ -197,16 +259,21 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (Linear layers as split-half f16 MFMA x3, f32 accumulate)" if args.precision == "f16x3" else "f32",
         "data": "synthetic",
-        "config": {"workload": desc, "name": args.workload, "points_per_gpu": N, "frames": T, "video": [H, W],
+        "config": {"workload": desc, "name": args.workload, "points_per_gpu": N, "frames": frames_per_step, "video": [H, W],
                    "iters": 6, "window_len": wl, "offline": offline, "sharding": f"points x{world}", "precision": args.precision,
                    "weights": "seeded synthetic (no checkpoints offline)"},
     }
+    if streaming:
+        result["config"]["hip_graph"] = bool(pred.model.hip_graph)
+        result["config"]["graph_nodes"] = next(iter(pred.model._graphs.values())).nodes if pred.model._graphs else 0
 
     if rank == 0 and not args.no_profile:
         # one extra step with the library's HIP-event recorder on (events on the launch stream)
+        if streaming:
+            pred.model.hip_graph = False  # events cannot be recorded inside a captured graph: profile the direct launches
         ops.profile_enable(True)
         t1 = time.perf_counter()
-        pred(video, grid_size=G)
+        step() if streaming else pred(video, grid_size=G)
         torch.cuda.synchronize()
         prof_step_s = time.perf_counter() - t1
         rows = ops.profile_read()
@@ -222,32 +289,14 @@ def main():
         result["kernels"] = kern
         result["profiled_step_ms"] = round(prof_step_s * 1e3, 1)
         result["hip_kernels_ms"] = round(sum(r["total_ms"] for r in rows), 1)
+        traffic = {}
+        if os.path.exists(args.pmc_traffic):
+            traffic = json.load(open(args.pmc_traffic))
         if rows:
-            top = rows[0]
-            ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
-            split = "f16x3" in top["name"]
-            peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-            result["roofline"] = {"kernel": top["name"], "bound": "mfma", "achieved": round(ach, 2),
-                                  "peak": peak, "unit": "TFLOP/s",
-                                  "frac": round(ach / peak, 4), "traffic": None,
-                                  "launches": top["launches"],
-                                  "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 1),
-                                  "flops_per_launch": top["flops"] / top["launches"]}
-            if split:
-                result["roofline"].update({
-                    "mfma_issued": round(3 * ach, 2), "mfma_issued_frac": round(3 * ach / peak, 4),
-                    "note": "achieved = ALGORITHMIC (f32-equivalent) flops / HIP-event time against the dense f16 MFMA peak; "
-                            "each product costs 3 f16 MFMAs (hi*hi + hi*lo + lo*hi), so the pipe itself runs at mfma_issued "
-                            "and the scheme's ceiling is peak/3 = 833 TF; the exact-f32 MFMA ceiling is 157 TF"})
-            else:
-                result["roofline"]["note"] = "fp32-input MFMA (exact f32) peak"
+            result["roofline"] = roofline_entry(rows[0], traffic)
             for r in rows:
-                if r["name"] == "corr_volume":
-                    gbs = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
-                    result["roofline_sampler"] = {"kernel": "corr_volume", "bound": "hbm", "achieved": round(gbs, 1),
-                                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                                  "traffic": None,
-                                                  "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 1)}
+                if r["name"].startswith("corr_volume"):
+                    result["roofline_sampler"] = roofline_entry(r, traffic, force_hbm=True)
     if rank == 0:
         result["parity"] = parity_probe(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -103,6 +103,7 @@ SYMBOLS = {
     "ctk_tap_indices": (C.c_int, [_P(WindowArgs), _fp, _fp]),
     "ctk_sample_patches": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_sample_support": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, _fp, _fp]),
+    "ctk_corrblock_sample": (C.c_int, [_P(_fp), _P(C.c_int32), _P(C.c_int32), C.c_int32, C.c_int32, _fp, _fp, _fp, _fp]),
     "ctk_normalize_to_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_avg_pool2_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_gemm": (C.c_int, [_P(GemmArgs), _fp]),

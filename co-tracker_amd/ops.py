@@ -180,6 +180,24 @@ def sample_patches(fmap_nhwc: torch.Tensor, coords: torch.Tensor, level: int) ->
     return out
 
 
+def corrblock_sample(pyr_nhwc: Sequence[torch.Tensor], targets: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """CorrBlock.corr + .sample fused (blocks.py:309-362): pyr_nhwc 4 x [S,H_l,W_l,128], targets [S,N,128],
+    coords [S,N,2] (level-0 units) -> [N,S,196].  The correlation volume is never materialised."""
+    _chk_f32(*pyr_nhwc, targets, coords)
+    assert len(pyr_nhwc) == L.LEVELS
+    S, N = coords.shape[0], coords.shape[1]
+    assert targets.shape == (S, N, 128) and coords.shape == (S, N, 2)
+    fm = (C.c_void_p * L.LEVELS)(*[_ptr(f) for f in pyr_nhwc])
+    Hs = (C.c_int32 * L.LEVELS)(*[f.shape[1] for f in pyr_nhwc])
+    Ws = (C.c_int32 * L.LEVELS)(*[f.shape[2] for f in pyr_nhwc])
+    for f in pyr_nhwc:
+        assert f.shape[0] == S and f.shape[3] == 128
+    out = torch.empty(N, S, L.LEVELS * 49, device=coords.device, dtype=torch.float32)
+    L.check(L.load().ctk_corrblock_sample(fm, Hs, Ws, S, N, _ptr(targets), _ptr(coords), _ptr(out), _stream()),
+            "ctk_corrblock_sample")
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # window-level ops
 # ------------------------------------------------------------------------------------------

@@ -184,6 +184,15 @@ int ctk_sample_patches(const float* fmap /*NHWC [S,H,W,128]*/, int32_t S, int32_
  * index relative to fmap[0]); coords [N,2] in this level's units; out [N,49,128].        */
 int ctk_sample_support(const float* fmap, int32_t T, int32_t H, int32_t W, const float* frames,
                        const float* coords, int32_t N, float* out, void* stream);
+/* CorrBlock.corr + CorrBlock.sample fused (cotracker/models/core/cotracker/blocks.py:284-362, CoTracker2's 4D
+ * correlation-volume sampler; num_levels=4, radius=3, padding_mode="border" as built at cotracker.py:119-124):
+ * out[n*S+s][l*49 + a*7 + b] = bilinear sample (grid_sampler_2d, align_corners) of the level-l volume
+ * <targets[s,n,:], fmaps_l[s,:,y,x]> / sqrt(128) at (x, y) = coords[s,n]/2^l + (a-3, b-3).  The volume is never
+ * materialised: only the <=9x9 footprint dots are formed.  fmaps[l]: NHWC [S,H[l],W[l],128] (level l>0 =
+ * ctk_avg_pool2_nhwc of level l-1, NOT normalised -- blocks.py:300-307); targets [S,N,128] (= track_feat,
+ * blocks.py:342); coords [S,N,2] level-0 units; out [N,S,196] (the reference's [B*N,S,LRR], blocks.py:338-339). */
+int ctk_corrblock_sample(const float* const* fmaps, const int32_t* H, const int32_t* W, int32_t S, int32_t N,
+                         const float* targets, const float* coords, float* out, void* stream);
 /* Channel L2-normalise + NCHW->NHWC (cotracker3_online.py:384-394) and 2x2 average pooling
  * (:401-409).  in [F,128,H,W] -> out NHWC [F,H,W,128]; pool: in NHWC [F,H,W,128] -> [F,H/2,W/2,128]. */
 int ctk_normalize_to_nhwc(const float* in, int32_t F, int32_t H, int32_t W, float* out, void* stream);

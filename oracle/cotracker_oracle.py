@@ -176,6 +176,79 @@ def corr_volume(corr_feat, support):
 
 
 # --------------------------------------------------------------------------
+# a-1 (4-D path) bilinear_sampler -> ATen grid_sampler_2d   model_utils.py:191-255
+# a-9  CorrBlock (CoTracker2)                              blocks.py:284-362
+# --------------------------------------------------------------------------
+def _fma32(a, b, c):
+    """float32 fused multiply-add: the f32 x f32 product is exact in float64."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+
+
+def bilinear_sampler_4d(inp, coords):
+    """bilinear_sampler(input[B,C,H,W], coords[B,Ho,Wo,2]=(x,y)) -> [B,C,Ho,Wo]  (model_utils.py:242-255,
+    align_corners=True, padding_mode="border") through ATen's vectorised CPU ``grid_sampler_2d``:
+    unnormalise (in+1)*((size-1)/2) (rounds like ((in+1)/2)*(size-1)), clip, x_w=floor, w=x-x_w, e=1-w, n=y-y_n,
+    s=1-n, weights nw=s*e, ne=s*w, sw=n*e, se=n*w, out-of-range corners gathered as 0, and
+    ``nw_val*nw + ne_val*ne + sw_val*sw + se_val*se`` accumulated left to right with FMA contraction
+    (pinned bit-exact by tests/golden/corrblock.npz)."""
+    inp = np.asarray(inp, dtype=f32)
+    coords = np.asarray(coords, dtype=f32)
+    B, C, H, W = inp.shape
+    xi, wx0, wx1 = sampler_indices_weights(coords[..., 0], W)
+    yi, wy0, wy1 = sampler_indices_weights(coords[..., 1], H)
+    out = np.zeros((B, C) + coords.shape[1:-1], dtype=f32)
+    for b in range(B):
+        acc = None
+        for dy, wy in ((0, wy0), (1, wy1)):
+            for dx, wx in ((0, wx0), (1, wx1)):
+                X, Y = xi[b] + dx, yi[b] + dy
+                ok = (X <= W - 1) & (Y <= H - 1)
+                v = inp[b][:, np.minimum(Y, H - 1), np.minimum(X, W - 1)]  # [C,Ho,Wo]
+                v = np.where(ok[None], v, f32(0))
+                w = (wy[b] * wx[b]).astype(f32)[None]
+                acc = (v * w).astype(f32) if acc is None else _fma32(v, w, acc)
+        out[b] = acc
+    return out
+
+
+def corrblock_pyramid(fmaps, num_levels=4):
+    """CorrBlock.__init__ (blocks.py:300-307): fmaps [B,S,C,H,W] + (num_levels-1) x avg_pool2d(2, stride=2)."""
+    return build_pyramid(fmaps, num_levels)
+
+
+def corrblock_corr(fmaps_pyramid, targets):
+    """CorrBlock.corr (blocks.py:342-362): targets [B,S,N,C] -> per level [B,S,N,H_l,W_l] = matmul / sqrt(C)."""
+    targets = np.asarray(targets, dtype=f32)
+    B, S, N, C = targets.shape
+    out = []
+    for fm in fmaps_pyramid:
+        fm = np.asarray(fm, dtype=f32)
+        H, W = fm.shape[-2:]
+        corrs = np.matmul(targets, fm.reshape(B, S, C, H * W)).astype(f32)
+        out.append((corrs / np.sqrt(f32(C))).astype(f32).reshape(B, S, N, H, W))
+    return out
+
+
+def corrblock_sample(corrs_pyramid, coords, r=3):
+    """CorrBlock.sample (blocks.py:309-340): coords [B,S,N,2] -> [B*N, S, levels*(2r+1)^2].
+    delta = stack(meshgrid(dy, dx, "ij")) is ADDED to (x, y): the first lattice index moves x, the second y."""
+    coords = np.asarray(coords, dtype=f32)
+    B, S, N, _ = coords.shape
+    d = np.linspace(-r, r, 2 * r + 1, dtype=f32)
+    g0, g1 = np.meshgrid(d, d, indexing="ij")
+    delta = np.stack([g0, g1], axis=-1).astype(f32)[None]  # [1,7,7,2]
+    outs = []
+    for i, corrs in enumerate(corrs_pyramid):
+        H, W = corrs.shape[-2:]
+        centroid = (coords.reshape(B * S * N, 1, 1, 2) / f32(2 ** i)).astype(f32)
+        lvl = (centroid + delta).astype(f32)
+        smp = bilinear_sampler_4d(np.asarray(corrs, dtype=f32).reshape(B * S * N, 1, H, W), lvl)
+        outs.append(smp.reshape(B, S, N, -1))
+    out = np.concatenate(outs, axis=-1)
+    return np.ascontiguousarray(np.transpose(out, (0, 2, 1, 3))).reshape(B * N, S, -1).astype(f32)
+
+
+# --------------------------------------------------------------------------
 # a-8d  Mlp / GELU / LayerNorm / Linear  blocks.py:40-76, 411-418
 # --------------------------------------------------------------------------
 def linear(x, w, b=None):

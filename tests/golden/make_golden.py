@@ -23,6 +23,7 @@ sys.path.insert(0, "/root/reference")
 from cotracker.models.core.model_utils import bilinear_sampler  # noqa: E402
 from cotracker.models.core.cotracker.cotracker3_online import CoTrackerThreeOnline, posenc  # noqa: E402
 from cotracker.models.core.cotracker.cotracker3_offline import CoTrackerThreeOffline  # noqa: E402
+from cotracker.models.core.cotracker.blocks import CorrBlock  # noqa: E402
 from cotracker.predictor import CoTrackerPredictor, CoTrackerOnlinePredictor  # noqa: E402
 
 from cotracker_amd.weights import fill_synthetic_  # noqa: E402
@@ -195,9 +196,39 @@ def gen_predictors():
     save("predictor.npz", **out)
 
 
+@torch.no_grad()
+def gen_corrblock():
+    """CoTracker2's CorrBlock (blocks.py:284-362) and the 4-D bilinear_sampler under it."""
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    # (i) 4-D sampler on single-channel maps: in range, out of range, integer and half-integer coordinates
+    for tag, (H, W) in dict(a=(16, 24), b=(3, 2), c=(1, 5)).items():
+        inp = torch.randn(6, 1, H, W, generator=g)
+        co = torch.rand(6, 7, 7, 2, generator=g) * torch.tensor([W + 6.0, H + 6.0]) - 3.0
+        co[:2] = co[:2].round()
+        co[2, ..., 0] = co[2, ..., 0].round() + 0.5
+        out[f"s4_{tag}_input"], out[f"s4_{tag}_coords"] = inp, co
+        out[f"s4_{tag}_output"] = bilinear_sampler(inp, co.clone(), padding_mode="border")
+    # (ii) CorrBlock as CoTracker2 builds it (cotracker.py:119-124): 4 levels, radius 3, border padding
+    B, S, N, C, H, W = 1, 3, 12, 128, 16, 24
+    fmaps = torch.randn(B, S, C, H, W, generator=g)
+    targets = torch.randn(B, S, N, C, generator=g)
+    coords = torch.rand(B, S, N, 2, generator=g) * torch.tensor([W + 4.0, H + 4.0]) - 2.0
+    coords[:, :, :3] = coords[:, :, :3].round()
+    coords[:, :, 3] = torch.tensor([0.0, 0.0])
+    coords[:, :, 4] = torch.tensor([W - 1.0, H - 1.0])
+    cb = CorrBlock(fmaps, num_levels=4, radius=3, padding_mode="border")
+    cb.corr(targets)
+    out.update(cb_fmaps=fmaps, cb_targets=targets, cb_coords=coords, cb_out=cb.sample(coords))
+    for i in range(4):
+        out[f"cb_corrs{i}"] = cb.corrs_pyramid[i]
+    save("corrblock.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_sampler()
     gen_ops()
     gen_models()
     gen_predictors()
+    gen_corrblock()

@@ -446,6 +446,42 @@ def test_forward_window_vs_oracle_random():
 
 
 # ------------------------------------------------------------------------------------------
+# CoTracker2's CorrBlock (blocks.py:284-362): fused corr + sample, volume never materialised
+# ------------------------------------------------------------------------------------------
+def test_corrblock_vs_reference_golden(golden):
+    from cotracker_amd.blocks import CorrBlock
+    g = golden("corrblock")
+    cb = CorrBlock(t(g["cb_fmaps"]), num_levels=4, radius=3, padding_mode="border")
+    cb.corr(t(g["cb_targets"]))
+    out = cb.sample(t(g["cb_coords"]))
+    assert out.shape == g["cb_out"].shape  # [B*N, S, 196]
+    # only the order of the 128-term dot products differs from the reference's BLAS matmul (|corr| ~ 3)
+    assert maxdiff(out, g["cb_out"]) < 3e-6
+
+
+def test_corrblock_vs_oracle_stress():
+    """Random features, coordinates far outside / on the border / integer / half-integer, odd level sizes."""
+    from cotracker_amd.blocks import CorrBlock
+    r = np.random.RandomState(3)
+    B, S, N, C, H, W = 2, 4, 37, 128, 20, 28
+    fm = r.standard_normal((B, S, C, H, W)).astype(np.float32)
+    tg = r.standard_normal((B, S, N, C)).astype(np.float32)
+    co = (r.uniform(-0.3, 1.3, size=(B, S, N, 2)) * np.array([W - 1, H - 1])).astype(np.float32)
+    co[:, :, :8] = np.round(co[:, :, :8])
+    co[:, :, 8:12] = np.round(co[:, :, 8:12]) + 0.5
+    co[:, :, 12] = [0.0, 0.0]
+    co[:, :, 13] = [W - 1.0, H - 1.0]
+    pyr = O.corrblock_pyramid(fm)
+    ref = O.corrblock_sample(O.corrblock_corr(pyr, tg), co)
+    cb = CorrBlock(t(fm), num_levels=4, radius=3, padding_mode="border")
+    cb.corr(t(tg))
+    out = cb.sample(t(co))
+    assert maxdiff(out, ref) < 5e-6
+    with pytest.raises(NotImplementedError):
+        CorrBlock(t(fm), num_levels=4, radius=4)
+
+
+# ------------------------------------------------------------------------------------------
 # models and predictors (encoder on PyTorch-ROCm + HIP hot path) vs reference goldens
 # ------------------------------------------------------------------------------------------
 def test_model_online_sliding_and_streaming(golden):

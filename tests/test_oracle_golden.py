@@ -154,3 +154,26 @@ def test_model_offline(golden):
     np.testing.assert_allclose(c, g["off_coords"], atol=1e-3, rtol=0)
     np.testing.assert_allclose(logit(v), logit(g["off_vis"]), atol=1e-4, rtol=0)
     np.testing.assert_allclose(logit(f), logit(g["off_conf"]), atol=1e-4, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------
+# CoTracker2's CorrBlock (blocks.py:284-362) and the 4-D bilinear_sampler under it
+# ------------------------------------------------------------------------------------------
+def test_sampler_4d_bit_exact(golden):
+    g = golden("corrblock")
+    for tag in "abc":
+        out = O.bilinear_sampler_4d(g[f"s4_{tag}_input"], g[f"s4_{tag}_coords"])
+        assert np.array_equal(out, g[f"s4_{tag}_output"]), tag
+
+
+def test_corrblock_oracle(golden):
+    g = golden("corrblock")
+    pyr = O.corrblock_pyramid(g["cb_fmaps"])
+    corrs = O.corrblock_corr(pyr, g["cb_targets"])
+    for i in range(4):
+        assert np.abs(corrs[i] - g[f"cb_corrs{i}"]).max() < 2e-6  # BLAS reduction order only
+    # sampling the reference's own volumes is bit-exact (indices, weights, FMA blend order)
+    out = O.corrblock_sample([g[f"cb_corrs{i}"] for i in range(4)], g["cb_coords"])
+    assert np.array_equal(out, g["cb_out"])
+    out = O.corrblock_sample(corrs, g["cb_coords"])
+    assert np.abs(out - g["cb_out"]).max() < 2e-6

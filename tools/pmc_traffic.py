@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Turn the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
+
+    pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md, section HBM: FETCH_SIZE / WRITE_SIZE are in
+KiB; on gfx950 FETCH_SIZE reports one half of the bytes of wide (16 B/lane) coalesced reads -> doubled here;
+WRITE_SIZE is uncalibrated and taken as reported.  Kernel names are mapped to the names of the library's HIP-event
+recorder (bench.py "kernels"), so bench.py can attach `traffic` to its roofline objects.  Means are over ALL
+dispatches of a kernel in the profiled command (the same population bench.py's per-launch averages use).
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+NAME_MAP = [
+    (r"gemm_sh_kernel<2, 2, 2, 2>", "gemm_sh_128x128"),
+    (r"gemm_sh_kernel<4, 2, 2, 2>", "gemm_sh_256x128"),
+    (r"gemm_sh_kernel<2, 2, 1, 1>", "gemm_sh_64x64"),
+    (r"gemm_f16x3_kernel<2, 2>", "gemm_f16x3_128x128"),
+    (r"gemm_f16x3_kernel<1, 1>", "gemm_f16x3_64x64"),
+    (r"gemm_f32_kernel<2, 2>", "gemm_f32_128x128"),
+    (r"gemm_f32_kernel<1, 1>", "gemm_f32_64x64"),
+    (r"corr_volume_sh_kernel", "corr_volume_sh"),
+    (r"corr_volume_kernel", "corr_volume"),
+    (r"attention_merge_kernel", "attention_merge"),
+    (r"attention_kernel", "attention"),
+    (r"attention_mfma", "attention"),
+    (r"layernorm_kernel", "layernorm"),
+    (r"assemble_kernel", "assemble_tokens"),
+    (r"heads_kernel", "heads_update"),
+    (r"split_rows_scaled_kernel", "pyramid_split"),
+    (r"virtual_init_kernel", "virtual_init"),
+]
+
+
+def short(kname):
+    for pat, nm in NAME_MAP:
+        if pat in kname:
+            return nm
+    m = re.search(r"(\w+)(<[^>]*>)?\(", kname)
+    return (m.group(1) if m else kname)[:48]
+
+
+def collect(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row.get("Kernel_Name", ""))
+            acc[k][0] += float(row["Counter_Value"])
+            acc[k][1] += 1
+    return acc
+
+
+def main():
+    fetch_csv, write_csv, out = sys.argv[1:4]
+    fetch = collect(fetch_csv, "FETCH_SIZE")
+    write = collect(write_csv, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        fb = 2.0 * 1024.0 * fetch[k][0] / max(fetch[k][1], 1) if k in fetch else None
+        wb = 1024.0 * write[k][0] / max(write[k][1], 1) if k in write else None
+        res[k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                  "hbm_bytes_per_launch": (fb or 0.0) + (wb or 0.0),
+                  "dispatches": fetch[k][1] if k in fetch else write[k][1],
+                  "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950), KiB -> B"}
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print(f"{k:28s} n={v['dispatches']:6d}  fetch {v['fetch_bytes_per_launch'] or 0:14.0f} B  write {v['write_bytes_per_launch'] or 0:14.0f} B")
+
+
+if __name__ == "__main__":
+    main()
