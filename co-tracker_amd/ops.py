@@ -270,6 +270,16 @@ class WindowGraph:
         self.ws = torch.empty(nbytes.value, device=win.device, dtype=torch.uint8)  # private: its address is baked in
         mw = weights.struct_for(win.S)
         h = C.c_void_p()
+        # One direct iteration first: every kernel of the window is resident (HIP loads code objects lazily, which
+        # is not allowed inside a capture); the state it touched is restored afterwards.
+        state = win.keep[2:5]
+        saved = [t_.clone() for t_ in state]
+        iters, win.args.iters = win.args.iters, 1
+        L.check(lib.ctk_forward_window(C.byref(win.args), C.byref(mw), _ptr(self.ws), self.ws.numel(), _stream()),
+                "ctk_forward_window")
+        win.args.iters = iters
+        for t_, s_ in zip(state, saved):
+            t_.copy_(s_)
         torch.cuda.synchronize(win.device)          # weight packing / input copies issued so far are complete
         L.check(lib.ctk_window_graph_create(C.byref(win.args), C.byref(mw), _ptr(self.ws), self.ws.numel(), C.byref(h)),
                 "ctk_window_graph_create")

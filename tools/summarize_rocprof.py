@@ -10,11 +10,15 @@ import sys
 from collections import defaultdict
 
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic import NAME_MAP  # noqa: E402  (library kernel -> HIP-event recorder name)
+
+
 def short(name):
+    for pat, nm in NAME_MAP:
+        if pat in name:
+            return f"{nm}  [{pat}]"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    for tag in ("gemm_f32_kernel<2, 2>", "gemm_f32_kernel<1, 1>"):
-        if tag in name:
-            return tag
     name = name.split("(")[0]
     return name[-70:]
 
