@@ -15,6 +15,7 @@
 #include "ctk_common.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
+#include <cstdlib>
 
 namespace {
 
@@ -159,6 +160,362 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MFMA kernels for the two space-attention shapes that carry ~90 % of the attention flops (4*S*64*N*384 each per
+// layer): points <- virtual (N queries x 64 keys) and virtual <- points (64 queries x N keys).  Products use the
+// split-half scheme of gemm_f16x3.hip (x = hi + lo IEEE halves, 3 x v_mfma_f32_32x32x16_f16, f32 accumulate,
+// ~2^-21 relative per product), so the result stays fp32-class while the contraction leaves the VALU.
+//
+// Both kernels compute the score tile TRANSPOSED, S'[key][query] = K . Q^T (K = first MFMA operand), so that a
+// lane owns ONE query (column lane & 31) and 16 of the tile's 32 keys in registers (row 8*(reg>>2) + 4*(lane>>5) +
+// (reg&3)); the softmax row reductions are then per-lane plus one exchange with lane ^ 32.  The probabilities
+// feed the second MFMA  O^T[dim][query] = V^T . P^T  straight from those registers as its B operand: B wants, for
+// k-step s and lane half h, 8 consecutive k values -- we simply DEFINE the k order inside each block of 16 keys as
+// k = 8h + e  <->  key = 16s + 8(e>>2) + 4h + (e&3)  (what the accumulator layout hands us) and build the V^T
+// operand with the same permutation.  No LDS round trip, no shuffles for P.
+// P is scaled by 2^12 before the split so that its lo half stays a normal f16 number.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KP = 56;              // K image row pitch in halves: 7 x 16-byte slots -> conflict-free ds_read_b128
+constexpr int VP = 72;              // V^T image row pitch in halves: 9 slots
+constexpr float PSCALE = 4096.0f;
+constexpr int QT_PER_WG = 4;        // 128-query tiles per workgroup of attention_kv64_kernel
+
+__device__ __forceinline__ f16x8 ctk_cat8(const f16x4 a, const f16x4 b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// 8 consecutive f32 (two float4) -> hi / lo f16x8
+__device__ __forceinline__ void ctk_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+  f16x4 ah, al, bh, bl;
+  ctk_split4(a, ah, al);
+  ctk_split4(b, bh, bl);
+  hi = ctk_cat8(ah, bh);
+  lo = ctk_cat8(al, bl);
+}
+__device__ __forceinline__ f32x16 ctk_mma3(const f16x8 ah, const f16x8 al, const f16x8 bh, const f16x8 bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);  // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  return acc;
+}
+
+// ---- n2 == 64 keys (points <- virtual, virtual self): workgroup = (frame b, head, QT_PER_WG x 128 queries) ----
+// K [64][48] and V^T [48][64 keys, permuted] of this (b, head) are split once into LDS; every wave then takes 32
+// queries at a time: Q fragment from global (scaled, split in registers), 18 MFMAs for S', in-register softmax,
+// 24 MFMAs for O^T, float4 / SH stores (a lane owns 4 consecutive output columns per register quad).
+__global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * 64 * KP + 2 * 64 * VP];
+  _Float16* kimg = lds;                 // [hi|lo][64 keys][KP]
+  _Float16* vimg = lds + 2 * 64 * KP;   // [hi|lo][64 dims (48 used)][VP]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r32 = lane & 31, half = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+
+  for (int i = tid; i < 64 * (HD / 4); i += 256) {
+    const int key = i / (HD / 4), d4 = i - key * (HD / 4);
+    const long row = ((long)b * p.kv_bs + (long)key * p.kv_is) * p.kv_ld + head * HD + d4 * 4;
+    const f32x4 kk = *reinterpret_cast<const f32x4*>(p.k + row);
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(p.v + row);
+    f16x4 hi, lo;
+    ctk_split4(kk, hi, lo);
+    *reinterpret_cast<f16x4*>(kimg + key * KP + d4 * 4) = hi;
+    *reinterpret_cast<f16x4*>(kimg + 64 * KP + key * KP + d4 * 4) = lo;
+    ctk_split4(vv, hi, lo);
+    const int ko = key & 15;
+    const int pos = (key & ~15) + 8 * ((ko >> 2) & 1) + 4 * (ko >> 3) + (ko & 3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      vimg[(d4 * 4 + e) * VP + pos] = hi[e];
+      vimg[64 * VP + (d4 * 4 + e) * VP + pos] = lo[e];
+    }
+  }
+  __syncthreads();
+
+  for (int qt = 0; qt < QT_PER_WG; ++qt) {
+    const int q0 = (blockIdx.x * QT_PER_WG + qt) * 128 + wave * 32;
+    if (q0 >= p.n1) break;  // wave-uniform
+    const int qi = min(q0 + r32, p.n1 - 1);
+    const float* qp = p.q + ((long)b * p.q_bs + (long)qi * p.q_is) * p.q_ld + head * HD + half * 8;
+    f16x8 qh[3], ql[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale;
+      ctk_split8(a, c, qh[j], ql[j]);
+    }
+    // S'[key][query]
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const _Float16* ka = kimg + (kt * 32 + r32) * KP + j * 16 + half * 8;
+        const f16x8 kh = *reinterpret_cast<const f16x8*>(ka);
+        const f16x8 kl = *reinterpret_cast<const f16x8*>(ka + 64 * KP);
+        sacc[kt] = ctk_mma3(kh, kl, qh[j], ql[j], sacc[kt]);
+      }
+    }
+    // softmax over the 64 keys of my query: 32 values here, 32 in lane ^ 32
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = expf(sacc[kt][e] - mx);
+        sum += pv;
+        sacc[kt][e] = pv * PSCALE;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    // O^T[dim][query] = V^T . P^T
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kt = s >> 1, base = 8 * (s & 1);
+      const f32x4 a = {sacc[kt][base], sacc[kt][base + 1], sacc[kt][base + 2], sacc[kt][base + 3]};
+      const f32x4 c = {sacc[kt][base + 4], sacc[kt][base + 5], sacc[kt][base + 6], sacc[kt][base + 7]};
+      f16x8 ph, pl;
+      ctk_split8(a, c, ph, pl);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const _Float16* va = vimg + (dt * 32 + r32) * VP + s * 16 + half * 8;
+        const f16x8 vh = *reinterpret_cast<const f16x8*>(va);
+        const f16x8 vl = *reinterpret_cast<const f16x8*>(va + 64 * VP);
+        oacc[dt] = ctk_mma3(vh, vl, ph, pl, oacc[dt]);
+      }
+    }
+    if (q0 + r32 < p.n1) {
+      const float inv = 1.0f / (sum * PSCALE);
+      const long orow = ((long)b * p.o_bs + (long)qi * p.o_is) * p.o_ld;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int d = dt * 32 + q * 8 + half * 4;
+          if (d < HD) {
+            const f32x4 t = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
+            if (p.o_split) {
+              f16x4 hi, lo;
+              ctk_split4(t, hi, lo);
+              _Float16* dst = reinterpret_cast<_Float16*>(p.out) + orow + ctk_sh_col(head * HD + d);
+              *reinterpret_cast<f16x4*>(dst) = hi;
+              *reinterpret_cast<f16x4*>(dst + 32) = lo;
+            } else {
+              *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
+            }
+          }
+        }
+    }
+  }
+}
+
+// ---- n1 == 64 queries (virtual <- points): workgroup = (key split, head, frame b), 4 waves --------------------
+// The 64 pre-scaled queries live in registers as the B operand for the whole key loop; wave w walks the split's
+// 32-key tiles w, w+4, ...: K fragment and the (permuted) V^T fragment come straight from global memory (each
+// element is used by exactly one lane; the next tile's loads are issued before this tile's MFMAs), online
+// softmax per query with the running max shared by the lane pair, then the four waves' (m, l, acc) states are
+// merged through LDS and written either as the final rows (one split) or as a partial for attention_merge_kernel.
+__global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
+  __shared__ float red[4][64][HD + 2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r32 = lane & 31, half = lane >> 5;
+  const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+
+  f16x8 qh[2][3], ql[2][3];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float* qp = p.q + ((long)b * p.q_bs + (long)(qt * 32 + r32) * p.q_is) * p.q_ld + head * HD + half * 8;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale;
+      ctk_split8(a, c, qh[qt][j], ql[qt][j]);
+    }
+  }
+  const int kbeg = split * p.keys_per_split;
+  const int kend = min(p.n2, kbeg + p.keys_per_split);
+  const int ntiles = (kend - kbeg + 31) >> 5;
+  const float* kbase = p.k + (long)b * p.kv_bs * p.kv_ld + head * HD + half * 8;
+  const float* vbase = p.v + (long)b * p.kv_bs * p.kv_ld + head * HD;
+  const long kstride = p.kv_is * p.kv_ld;
+  const int vd0 = r32, vd1 = min(32 + r32, HD - 1);  // dims of my V^T rows (rows 48..63 of the 2nd tile: unused outputs)
+
+  f32x4 kraw[6];
+  float vraw[2][16];
+  auto load_tile = [&](int tile) {
+    const int k0 = kbeg + tile * 32;
+    const float* kp = kbase + (long)min(k0 + r32, kend - 1) * kstride;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      kraw[2 * j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
+      kraw[2 * j + 1] = *reinterpret_cast<const f32x4*>(kp + 16 * j + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = min(k0 + 16 * s + 8 * (e >> 2) + 4 * half + (e & 3), kend - 1);
+        const float* vp = vbase + (long)key * kstride;
+        vraw[0][s * 8 + e] = vp[vd0];
+        vraw[1][s * 8 + e] = vp[vd1];
+      }
+  };
+
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
+  f32x16 oacc[2][2];  // [dim tile][query tile]
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][qt][e] = 0.0f;
+
+  if (wave < ntiles) load_tile(wave);
+  for (int tile = wave; tile < ntiles; tile += 4) {
+    const int k0 = kbeg + tile * 32;
+    f16x8 kh[3], kl[3], vh[2][2], vl[2][2];  // V: [dim tile][k-step]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ctk_split8(kraw[2 * j], kraw[2 * j + 1], kh[j], kl[j]);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 a = {vraw[dt][s * 8], vraw[dt][s * 8 + 1], vraw[dt][s * 8 + 2], vraw[dt][s * 8 + 3]};
+        const f32x4 c = {vraw[dt][s * 8 + 4], vraw[dt][s * 8 + 5], vraw[dt][s * 8 + 6], vraw[dt][s * 8 + 7]};
+        ctk_split8(a, c, vh[dt][s], vl[dt][s]);
+      }
+    if (tile + 4 < ntiles) load_tile(tile + 4);  // raw registers are free again: prefetch behind the MFMAs
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[qt][e] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sacc[qt] = ctk_mma3(kh[j], kl[j], qh[qt][j], ql[qt][j], sacc[qt]);
+    }
+    if (k0 + 32 > kend) {  // ragged last tile: keys past the split's range get probability 0
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = k0 + 8 * (e >> 2) + 4 * half + (e & 3);
+        if (key >= kend) {
+          sacc[0][e] = -INFINITY;
+          sacc[1][e] = -INFINITY;
+        }
+      }
+    }
+    f16x8 ph[2][2], pl[2][2];  // [query tile][k-step]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[qt][e]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(m[qt], tmax);       // finite: every tile holds at least one valid key
+      const float alpha = expf(m[qt] - mnew);      // m = -inf on the first tile -> 0
+      m[qt] = mnew;
+      float psum = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = expf(sacc[qt][e] - mnew);
+        psum += pv;
+        sacc[qt][e] = pv * PSCALE;
+      }
+      l[qt] = l[qt] * alpha + psum;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        oacc[0][qt][e] *= alpha;
+        oacc[1][qt][e] *= alpha;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 a = {sacc[qt][8 * s], sacc[qt][8 * s + 1], sacc[qt][8 * s + 2], sacc[qt][8 * s + 3]};
+        const f32x4 c = {sacc[qt][8 * s + 4], sacc[qt][8 * s + 5], sacc[qt][8 * s + 6], sacc[qt][8 * s + 7]};
+        ctk_split8(a, c, ph[qt][s], pl[qt][s]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = ctk_mma3(vh[dt][s], vl[dt][s], ph[qt][s], pl[qt][s], oacc[dt][qt]);
+  }
+
+  // merge the four waves' states
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float lsum = l[qt] + __shfl_xor(l[qt], 32, 64);
+    float* rr = &red[wave][qt * 32 + r32][0];
+    if (half == 0) {
+      rr[0] = m[qt];
+      rr[1] = lsum;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int d = dt * 32 + q * 8 + half * 4;
+        if (d < HD) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rr[2 + d + e] = oacc[dt][qt][4 * q + e] * (1.0f / PSCALE);
+        }
+      }
+  }
+  __syncthreads();
+  {
+    const int qi = tid >> 2, part = tid & 3;  // 64 queries x 4 groups of 12 dims
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[w][qi][0]);
+    float L = 0.0f, o[12];
+#pragma unroll
+    for (int d = 0; d < 12; ++d) o[d] = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float wm = red[w][qi][0];
+      const float wgt = (wm == -INFINITY) ? 0.0f : expf(wm - mm);  // waves that saw no tile carry m = -inf, l = 0
+      L += wgt * red[w][qi][1];
+#pragma unroll
+      for (int d = 0; d < 12; ++d) o[d] += wgt * red[w][qi][2 + part * 12 + d];
+    }
+    if (p.splits == 1) {
+      const float inv = 1.0f / L;
+      const long orow = ((long)b * p.o_bs + (long)qi * p.o_is) * p.o_ld;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const f32x4 t = {o[4 * i] * inv, o[4 * i + 1] * inv, o[4 * i + 2] * inv, o[4 * i + 3] * inv};
+        const int col = head * HD + part * 12 + 4 * i;
+        if (p.o_split) {
+          f16x4 hi, lo;
+          ctk_split4(t, hi, lo);
+          _Float16* dst = reinterpret_cast<_Float16*>(p.out) + orow + ctk_sh_col(col);
+          *reinterpret_cast<f16x4*>(dst) = hi;
+          *reinterpret_cast<f16x4*>(dst + 32) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(p.out + orow + col) = t;
+        }
+      }
+    } else {
+      float* pp = p.partial + ((((long)split * p.nbatch + b) * CTK_HEADS + head) * p.n1 + qi) * (HD + 2);
+      if (part == 0) {
+        pp[0] = mm;
+        pp[1] = L;
+      }
+#pragma unroll
+      for (int d = 0; d < 12; ++d) pp[2 + part * 12 + d] = o[d];
+    }
+  }
+}
+
 __global__ void attention_merge_kernel(AttnP p) {
   // one thread per (batch, head, query, dim)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,6 +547,15 @@ __global__ void attention_merge_kernel(AttnP p) {
   }
 }
 
+// Dev knob (read once): CTK_ATTN = 0 auto (MFMA kernels for the 64-key / 64-query shapes) | 1 VALU kernel everywhere.
+int attn_backend() {
+  static const int v = [] {
+    const char* e = getenv("CTK_ATTN");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 }  // namespace
 
 extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
@@ -207,9 +573,43 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
   p.splits = a->splits > 1 ? a->splits : 1;
   if (p.splits > 1 && !a->partial) return CTK_E_NULL;
   p.partial = a->partial;
+  p.scale = 0.14433756729740643f;  // 48 ** -0.5 (blocks.py:372)
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double flops = 4.0 * a->nbatch * (double)a->n1 * a->n2 * CTK_HID;
+  const double bytes = 4.0 * a->nbatch * ((double)a->n1 * 2 + (double)a->n2 * 2) * CTK_HID;
+  const bool mfma = attn_backend() == 0;  // CTK_ATTN=1 forces the VALU kernel everywhere (A/B knob)
+
+  if (mfma && a->n2 == CTK_VIRT) {
+    // points <- virtual / virtual self: all 64 keys in one pass, no key split
+    p.splits = 1;
+    p.keys_per_split = a->n2;
+    p.bpw = 1;
+    p.qtiles = 1;
+    CtkProfScope ps(a->n1 > CTK_VIRT ? "attention_p2v" : "attention_vself", flops, bytes, s);
+    const unsigned gx = (unsigned)((a->n1 + 128 * QT_PER_WG - 1) / (128 * QT_PER_WG));
+    hipLaunchKernelGGL(attention_kv64_kernel, dim3(gx, CTK_HEADS, (unsigned)a->nbatch), dim3(256), 0, s, p);
+    CTK_HIP_CHECK_LAUNCH();
+    return CTK_OK;
+  }
+  if (mfma && a->n1 == CTK_VIRT && a->n2 > CTK_VIRT) {
+    // virtual <- points: key range split over workgroups, 32-key tiles
+    p.keys_per_split = ((a->n2 + p.splits - 1) / p.splits + 31) / 32 * 32;
+    p.splits = (a->n2 + p.keys_per_split - 1) / p.keys_per_split;  // drop empty splits
+    p.bpw = 1;
+    p.qtiles = 1;
+    CtkProfScope ps("attention_v2p", flops, bytes, s);
+    hipLaunchKernelGGL(attention_q64_kernel, dim3((unsigned)p.splits, CTK_HEADS, (unsigned)a->nbatch), dim3(256), 0, s, p);
+    CTK_HIP_CHECK_LAUNCH();
+    if (p.splits > 1) {
+      const long total = (long)p.nbatch * CTK_HEADS * p.n1 * HD;
+      hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+      CTK_HIP_CHECK_LAUNCH();
+    }
+    return CTK_OK;
+  }
+
   p.keys_per_split = ((a->n2 + p.splits - 1) / p.splits + KC - 1) / KC * KC;
   p.splits = (a->n2 + p.keys_per_split - 1) / p.keys_per_split;  // drop empty splits
-  p.scale = 0.14433756729740643f;  // 48 ** -0.5 (blocks.py:372)
   unsigned gx;
   if (a->n1 >= 64) {
     p.bpw = 1;
@@ -221,9 +621,10 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
     p.qtiles = 1;
     gx = (unsigned)((a->nbatch + p.bpw - 1) / p.bpw);
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  CtkProfScope ps("attention", 4.0 * a->nbatch * (double)a->n1 * a->n2 * CTK_HID,
-                  4.0 * a->nbatch * ((double)a->n1 * 2 + (double)a->n2 * 2) * CTK_HID, s);
+  // one recorder row per use of the kernel on the path: time axis / points<-virtual / virtual<-points / virtual self
+  const char* pname = p.splits > 1 ? "attention_v2p" : (a->n1 > CTK_VIRT && a->n2 == CTK_VIRT) ? "attention_p2v"
+                      : (a->n1 == CTK_VIRT && a->n2 == CTK_VIRT && a->q_is != 1) ? "attention_vself" : "attention_time";
+  CtkProfScope ps(pname, flops, bytes, s);
   const size_t lds_bytes = (size_t)2 * p.bpw * (KC * HD + BPAD) * sizeof(float);
   hipLaunchKernelGGL(attention_kernel, dim3(gx, CTK_HEADS, (unsigned)p.splits), dim3(64), lds_bytes, s, p);
   CTK_HIP_CHECK_LAUNCH();

@@ -68,7 +68,8 @@ def main():
                   "hbm_bytes_per_launch": (fb or 0.0) + (wb or 0.0),
                   "dispatches": fetch[k][1] if k in fetch else write[k][1],
                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950), KiB -> B"}
-    json.dump(res, open(out, "w"), indent=1)
+    lib_names = {nm for _, nm in NAME_MAP}
+    json.dump({k: v for k, v in res.items() if k in lib_names}, open(out, "w"), indent=1)  # library kernels only (others are printed)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:28s} n={v['dispatches']:6d}  fetch {v['fetch_bytes_per_launch'] or 0:14.0f} B  write {v['write_bytes_per_launch'] or 0:14.0f} B")
 
