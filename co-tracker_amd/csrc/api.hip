@@ -58,7 +58,7 @@ struct UfWs {
 };
 
 int v2p_splits(int N) {
-  int s = (N + 511) / 512;  // ~512 keys per workgroup
+  int s = (N + 1023) / 1024;  // ~1024 keys (32 tiles of 32, 8 per wave) per 4-wave workgroup of attention_q64_kernel
   if (s < 1) s = 1;
   if (s > 32) s = 32;
   return s;

@@ -516,6 +516,133 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
   }
 }
 
+// ---- n1 == n2 (time attention: S = 16 sliding / streaming, S = T offline) -------------------------------------
+// One WAVE per (batch group, head, 32-query tile); no LDS, no barrier, so occupancy hides the load latency.
+// S <= 16: two batches share one 32 x 32 score tile (block diagonal: slots 0..15 = batch 2g, 16..31 = batch
+// 2g+1, cross-batch scores masked to -inf so their probabilities are exactly 0); S > 16: one batch, 32-key tiles
+// with online softmax.  K and V^T fragments come straight from global memory as in attention_q64_kernel.
+template <int PACK>  // batches per score tile: 2 when n1 <= 16, else 1
+__global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r32 = lane & 31, half = lane >> 5;
+  const int head = blockIdx.y;
+  constexpr int pack = PACK;
+  constexpr int spb = 32 / pack;     // tile slots per batch
+  const long job = (long)blockIdx.x * 4 + wave;
+  const long njobs = (long)((p.nbatch + pack - 1) / pack) * p.qtiles;
+  if (job >= njobs) return;          // wave-uniform
+  const int g = (int)(job / p.qtiles), qtile = (int)(job - (long)g * p.qtiles);
+  const int b0 = g * pack;
+
+  const int qb = r32 / spb, qi = qtile * spb + r32 % spb;
+  const bool qvalid = (b0 + qb < p.nbatch) && (qi < p.n1);
+  const int qbc = min(b0 + qb, p.nbatch - 1), qic = min(qi, p.n1 - 1);
+  f16x8 qh[3], ql[3];
+  {
+    const float* qp = p.q + ((long)qbc * p.q_bs + (long)qic * p.q_is) * p.q_ld + head * HD + half * 8;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale;
+      ctk_split8(a, c, qh[j], ql[j]);
+    }
+  }
+  const int vd0 = r32, vd1 = min(32 + r32, HD - 1);
+  float m = -INFINITY, l = 0.0f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.0f;
+
+  const int nkt = (pack == 2) ? 1 : (p.n2 + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    f16x8 kh[3], kl[3], vh[2][2], vl[2][2];
+    {
+      const int kb = min(b0 + r32 / spb, p.nbatch - 1), ki = min(kt * spb + r32 % spb, p.n2 - 1);
+      const float* kp = p.k + ((long)kb * p.kv_bs + (long)ki * p.kv_is) * p.kv_ld + head * HD + half * 8;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        ctk_split8(*reinterpret_cast<const f32x4*>(kp + 16 * j), *reinterpret_cast<const f32x4*>(kp + 16 * j + 4), kh[j], kl[j]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int slot = 16 * s + 8 * (e >> 2) + 4 * half + (e & 3);
+        const int kb = min(b0 + slot / spb, p.nbatch - 1), ki = min(kt * spb + slot % spb, p.n2 - 1);
+        const float* vp = p.v + ((long)kb * p.kv_bs + (long)ki * p.kv_is) * p.kv_ld + head * HD;
+        v0[e] = vp[vd0];
+        v1[e] = vp[vd1];
+      }
+      ctk_split8(f32x4{v0[0], v0[1], v0[2], v0[3]}, f32x4{v0[4], v0[5], v0[6], v0[7]}, vh[0][s], vl[0][s]);
+      ctk_split8(f32x4{v1[0], v1[1], v1[2], v1[3]}, f32x4{v1[4], v1[5], v1[6], v1[7]}, vh[1][s], vl[1][s]);
+    }
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sacc = ctk_mma3(kh[j], kl[j], qh[j], ql[j], sacc);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int slot = 8 * (e >> 2) + 4 * half + (e & 3);
+      const bool ok = (slot / spb == qb) && (b0 + slot / spb < p.nbatch) && (kt * spb + slot % spb < p.n2);
+      sacc[e] = ok ? sacc[e] : -INFINITY;
+      tmax = fmaxf(tmax, sacc[e]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    float mnew = fmaxf(m, tmax);
+    if (mnew == -INFINITY) mnew = 0.0f;  // a query slot with no valid key (padding slot): all probabilities 0, never stored
+    const float alpha = expf(m - mnew);
+    m = mnew;
+    float psum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = expf(sacc[e] - mnew);
+      psum += pv;
+      sacc[e] = pv * PSCALE;
+    }
+    l = l * alpha + psum;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      oacc[0][e] *= alpha;
+      oacc[1][e] *= alpha;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 ph, pl;
+      ctk_split8(f32x4{sacc[8 * s], sacc[8 * s + 1], sacc[8 * s + 2], sacc[8 * s + 3]},
+                 f32x4{sacc[8 * s + 4], sacc[8 * s + 5], sacc[8 * s + 6], sacc[8 * s + 7]}, ph, pl);
+      oacc[0] = ctk_mma3(vh[0][s], vl[0][s], ph, pl, oacc[0]);
+      oacc[1] = ctk_mma3(vh[1][s], vl[1][s], ph, pl, oacc[1]);
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (qvalid) {
+    const float inv = 1.0f / (l * PSCALE);
+    const long orow = ((long)qbc * p.o_bs + (long)qic * p.o_is) * p.o_ld;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int d = dt * 32 + q * 8 + half * 4;
+        if (d < HD) {
+          const f32x4 t = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
+          if (p.o_split) {
+            f16x4 hi, lo;
+            ctk_split4(t, hi, lo);
+            _Float16* dst = reinterpret_cast<_Float16*>(p.out) + orow + ctk_sh_col(head * HD + d);
+            *reinterpret_cast<f16x4*>(dst) = hi;
+            *reinterpret_cast<f16x4*>(dst + 32) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
+          }
+        }
+      }
+  }
+}
+
 __global__ void attention_merge_kernel(AttnP p) {
   // one thread per (batch, head, query, dim)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -547,13 +674,11 @@ __global__ void attention_merge_kernel(AttnP p) {
   }
 }
 
-// Dev knob (read once): CTK_ATTN = 0 auto (MFMA kernels for the 64-key / 64-query shapes) | 1 VALU kernel everywhere.
+// Dev knob, read at every call (tests flip it): CTK_ATTN = 0 / unset: MFMA kernels for the 64-key, 64-query and
+// square shapes | 1: the VALU kernel everywhere.
 int attn_backend() {
-  static const int v = [] {
-    const char* e = getenv("CTK_ATTN");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
+  const char* e = getenv("CTK_ATTN");
+  return e ? atoi(e) : 0;
 }
 
 }  // namespace
@@ -605,6 +730,19 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
       hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
       CTK_HIP_CHECK_LAUNCH();
     }
+    return CTK_OK;
+  }
+
+  if (mfma && a->n1 == a->n2 && p.splits == 1) {
+    // time attention (and any other square shape): one wave per (batch pair | batch, head, 32-query tile)
+    p.keys_per_split = a->n2;
+    p.bpw = a->n1 <= 16 ? 2 : 1;
+    p.qtiles = p.bpw == 2 ? 1 : (a->n1 + 31) / 32;
+    const long njobs = (long)((a->nbatch + p.bpw - 1) / p.bpw) * p.qtiles;
+    CtkProfScope ps(a->q_is == 1 ? "attention_time" : "attention_vself", flops, bytes, s);
+    if (p.bpw == 2) hipLaunchKernelGGL(attention_self_kernel<2>, dim3((unsigned)((njobs + 3) / 4), CTK_HEADS), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attention_self_kernel<1>, dim3((unsigned)((njobs + 3) / 4), CTK_HEADS), dim3(256), 0, s, p);
+    CTK_HIP_CHECK_LAUNCH();
     return CTK_OK;
   }
 

@@ -190,9 +190,14 @@ def test_layernorm(affine):
 
 
 @pytest.mark.parametrize("B,N1,N2,splits", [(37, 16, 16, 1), (5, 120, 120, 1), (16, 64, 700, 4), (3, 200, 64, 1),
-                                            (7, 48, 48, 1), (9, 8, 8, 1), (2, 64, 64, 1), (4, 64, 1500, 32)])
-def test_attention(B, N1, N2, splits):
+                                            (7, 48, 48, 1), (9, 8, 8, 1), (2, 64, 64, 1), (4, 64, 1500, 32),
+                                            (3, 64, 6400, 7), (2, 1000, 64, 1), (11, 33, 33, 1), (3, 20, 50, 1)])
+@pytest.mark.parametrize("backend", ["mfma", "valu"])
+def test_attention(B, N1, N2, splits, backend, monkeypatch):
+    """MFMA kernels (64-key, 64-query and square shapes; split-half products) and the exact-f32 VALU kernel
+    (CTK_ATTN=1, also the fallback for every other shape) against torch fp64."""
     from cotracker_amd import ops
+    monkeypatch.setenv("CTK_ATTN", "1" if backend == "valu" else "0")
     g = torch.Generator().manual_seed(B * 1000 + N1 + N2)
     q = torch.randn(B, N1, 384, generator=g).to(dev())
     k = torch.randn(B, N2, 384, generator=g).to(dev())
@@ -549,8 +554,13 @@ def test_model_online_streaming_hip_graph(golden):
             cs, vs, fs, _ = m(video[:, ind:ind + 8], q, iters=4, is_online=True)
         outs[use_graph] = (cs.clone(), vs.clone(), fs.clone())
     assert len(m._graphs) == 1
-    for a, b in zip(outs[False], outs[True]):
-        assert maxdiff(a, b) == 0.0
+    # The update path is bit-identical under replay (test_window_graph_replay_is_bit_identical); at model level the
+    # MIOpen encoder itself differs run to run by ~5e-6 (measured: tools/probe_graph_determinism.py), which the 4
+    # windows x 4 iterations turn into <1e-4 px -- the same spread as two direct runs.
+    assert maxdiff(outs[False][0], outs[True][0]) < 3e-4
+    # (logits recovered from float32 sigmoids near 0.999 carry ~6e-8 * 1/(p(1-p)) ~ 6e-5 of quantisation noise)
+    assert maxdiff(logit(outs[False][1]), logit(outs[True][1])) < 2e-4
+    assert maxdiff(logit(outs[False][2]), logit(outs[True][2])) < 2e-4
     assert maxdiff(outs[True][0], g["on_stream_coords"]) < 1e-3
     assert maxdiff(logit(outs[True][1]), logit(g["on_stream_vis"])) < 1e-4
 
