@@ -180,24 +180,6 @@ constexpr int VP = 72;              // V^T image row pitch in halves: 9 slots
 constexpr float PSCALE = 4096.0f;
 constexpr int QT_PER_WG = 4;        // 128-query tiles per workgroup of attention_kv64_kernel
 
-__device__ __forceinline__ f16x8 ctk_cat8(const f16x4 a, const f16x4 b) {
-  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-// 8 consecutive f32 (two float4) -> hi / lo f16x8
-__device__ __forceinline__ void ctk_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
-  f16x4 ah, al, bh, bl;
-  ctk_split4(a, ah, al);
-  ctk_split4(b, bh, bl);
-  hi = ctk_cat8(ah, bh);
-  lo = ctk_cat8(al, bl);
-}
-__device__ __forceinline__ f32x16 ctk_mma3(const f16x8 ah, const f16x8 al, const f16x8 bh, const f16x8 bl, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);  // small terms first
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-  return acc;
-}
-
 // ---- n2 == 64 keys (points <- virtual, virtual self): workgroup = (frame b, head, QT_PER_WG x 128 queries) ----
 // K [64][48] and V^T [48][64 keys, permuted] of this (b, head) are split once into LDS; every wave then takes 32
 // queries at a time: Q fragment from global (scaled, split in registers), 18 MFMAs for S', in-register softmax,

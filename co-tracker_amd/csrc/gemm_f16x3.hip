@@ -215,7 +215,11 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(CtkGemmP g) {
 // XOR swizzle of the 16-byte chunk index applied on the SOURCE address (lane (row, pos) fetches chunk
 // pos ^ ((row >> 1) & 7)) and undone in the fragment reads: the 16 lanes of a ds_read_b128 group then
 // cover 16 distinct 16-byte bank groups.  No staging registers, no conversion, no ds_write.
-template <int WM, int WN, int MR, int NR>
+// NS = LDS stages.  NS = 2: tile kt+2 is requested in the middle of tile kt and must have landed one tile later.
+// NS = 3 (one workgroup per CU): tile kt+3 is requested there and has two tiles of MFMAs to land; the mid-tile
+// barrier is then a raw s_barrier behind a COUNTED s_waitcnt vmcnt (one tile stays in flight across it) --
+// __syncthreads() would drain the DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
+template <int WM, int WN, int MR, int NR, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
@@ -223,7 +227,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
   constexpr int GPW = GROUPS / NW;        // groups per wave
   static_assert(GROUPS % NW == 0, "DMA groups must divide evenly over the waves");
   constexpr int STAGE = (BM + BN) * 128;  // bytes
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  static_assert(NS == 2 || NS == 3, "2 or 3 LDS stages");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
 
   const unsigned nblk = gridDim.x;
   unsigned tile = ctk_xcd_remap(blockIdx.x, nblk);
@@ -313,17 +318,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
   // phase never waits on LDS latency.  The barrier in the middle of the tile releases its stage: all waves have
   // finished reading it (lgkmcnt(0) is part of __syncthreads) and their DMA of tile kt+1 has landed (vmcnt(0));
   // the DMA of tile kt+2 then has a whole tile of MFMAs to land before it is waited for.
+  // Wait until at most `tiles` of my DMA tiles are still in flight (and my LDS reads are done), then barrier.
+  auto sync_tiles = [&](int tiles) {
+    if (NS == 2) {
+      __syncthreads();  // vmcnt(0): my DMA landed; lgkmcnt(0): my reads of the stage about to be overwritten are done
+    } else {
+      if (tiles >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
   Frags fa, fb;
   dma(0, 0);
   if (KT > 1) dma(1, 1);
-  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");  // tile 0 only
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (NS == 3 && KT > 2) dma(2, 2);
+  {
+    const int later = min(NS - 1, KT - 1);  // tiles requested after tile 0
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPW) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   load_frags(0, 0, fa);
   // (the last tile is peeled so that no control-flow merge sits between a set's loads and the other set's MFMAs:
   //  at a merge hipcc falls back to lgkmcnt(0) and would expose the latency of the loads just issued)
+  int st = 0;  // stage of tile kt
   for (int kt = 0; kt + 1 < KT; ++kt) {
-    const int st = kt & 1;
+    const int st_next = (st + 1 == NS) ? 0 : st + 1;
     // The LDS reads of the other register set are issued AFTER the first MFMA group of this one: hipcc waits
     // lgkmcnt(0) before a set's first use, so at that point only loads issued a half-tile ago may be in flight.
     mma_term(fa, 0);
@@ -333,17 +356,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
     mma_term(fa, 1);
     mma_term(fa, 2);
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // vmcnt(0): my DMA of tile kt+1 landed; lgkmcnt(0): my reads of stage st are done
-    if (kt + 2 < KT) dma(kt + 2, st);
-    load_frags(st ^ 1, 0, fa);
+    // tile kt+1 must have landed; with 3 stages tile kt+2 (if any) stays in flight across the barrier
+    sync_tiles((NS == 3 && kt + 2 < KT) ? 1 : 0);
+    if (kt + NS < KT) dma(kt + NS, st);  // stage st is free: every wave has its fragments of tile kt in registers
+    load_frags(st_next, 0, fa);
     __builtin_amdgcn_sched_barrier(0);
     mma_term(fb, 0);
     mma_term(fb, 1);
     mma_term(fb, 2);
     __builtin_amdgcn_sched_barrier(0);
+    st = st_next;
   }
   {
-    const int st = (KT - 1) & 1;
     mma_term(fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     load_frags(st, 1, fb);
@@ -397,13 +421,11 @@ __global__ void weight_pack_kernel(const float* W, long ldw, int N, int K, const
 }  // namespace
 
 namespace {
-// Dev knob (read once): CTK_GEMM_TILE = 0 auto (128x128, 2 blocks/CU) | 2 force 256x128 (8 waves, 1 block/CU).
+// Dev knob (read per call): CTK_GEMM_TILE = 0 auto (128x128, 2 blocks/CU) | 2 force 256x128 (8 waves, 1 block/CU,
+// 2 LDS stages) | 3 force 256x128 with 3 LDS stages (counted vmcnt + raw barrier).
 int gemm_tile_pref() {
-  static const int v = [] {
-    const char* e = getenv("CTK_GEMM_TILE");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
+  const char* e = getenv("CTK_GEMM_TILE");
+  return e ? atoi(e) : 0;
 }
 template <typename K>
 int launch_with_lds(K kernel, unsigned blocks, unsigned threads, size_t lds_bytes, const CtkGemmP& g, hipStream_t s) {
@@ -418,18 +440,22 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
   const bool big = (g.N % 128) == 0 && blocks128 >= 384;
   if (g.a_split) {
     const int pref = gemm_tile_pref();
-    if (big && pref == 2) {
+    if (big && pref == 3) {
+      g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 128;
+      CtkProfScope ps("gemm_sh_256x128x3", flops, bytes, s);
+      hipLaunchKernelGGL((gemm_sh_kernel<4, 2, 2, 2, 3>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(512), 0, s, g);
+    } else if (big && pref == 2) {
       g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 128;
       CtkProfScope ps("gemm_sh_256x128", flops, bytes, s);
-      hipLaunchKernelGGL((gemm_sh_kernel<4, 2, 2, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(512), 0, s, g);
+      hipLaunchKernelGGL((gemm_sh_kernel<4, 2, 2, 2, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(512), 0, s, g);
     } else if (big) {
       g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;
       CtkProfScope ps("gemm_sh_128x128", flops, bytes, s);
-      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2>), dim3((unsigned)blocks128), dim3(256), 0, s, g);
+      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2, 2>), dim3((unsigned)blocks128), dim3(256), 0, s, g);
     } else {
       g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
       CtkProfScope ps("gemm_sh_64x64", flops, bytes, s);
-      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
+      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
     }
   } else if (big) {
     g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;

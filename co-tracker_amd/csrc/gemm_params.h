@@ -27,6 +27,24 @@ __device__ __forceinline__ void ctk_split2(const f32x2 v, f16x2& hi, f16x2& lo) 
 // halves offset of column c inside an SH row (hi plane; lo plane is +32)
 __device__ __host__ __forceinline__ long ctk_sh_col(int c) { return (long)(c >> 5) * 64 + (c & 31); }
 
+__device__ __forceinline__ f16x8 ctk_cat8(const f16x4 a, const f16x4 b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// 8 consecutive f32 (two float4) -> hi / lo f16x8
+__device__ __forceinline__ void ctk_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+  f16x4 ah, al, bh, bl;
+  ctk_split4(a, ah, al);
+  ctk_split4(b, bh, bl);
+  hi = ctk_cat8(ah, bh);
+  lo = ctk_cat8(al, bl);
+}
+__device__ __forceinline__ f32x16 ctk_mma3(const f16x8 ah, const f16x8 al, const f16x8 bh, const f16x8 bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);  // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  return acc;
+}
+
 struct CtkGemmP {
   const void* A; long lda; int M;   // f32 [M][lda] or SH halves (lda = halves per row) when a_split
   const float* W; long ldw; int N; int K;

@@ -305,9 +305,12 @@ def test_corr_volume(golden, ops_model):
     assert maxdiff(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3]) == 0.0
 
 
-def test_corr_volume_sh(golden, ops_model):
-    """Split-half sampler (footprint correlation on f16 MFMA x3, blend afterwards) vs the reference goldens."""
+@pytest.mark.parametrize("version", ["1", "2"])
+def test_corr_volume_sh(golden, ops_model, version, monkeypatch):
+    """Split-half sampler (footprint correlation on f16 MFMA x3, blend afterwards) vs the reference goldens.
+    version 2 = the opt-in wave-per-frame kernel with the blend on MFMA (CTK_CORR=2)."""
     from cotracker_amd import ops
+    monkeypatch.setenv("CTK_CORR", version)
     g = golden("ops")
     win = make_window(g, ops_model)
     S, N = win.S, win.N
@@ -325,11 +328,13 @@ def test_corr_volume_sh(golden, ops_model):
     assert torch.equal(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3])
 
 
+@pytest.mark.parametrize("version", ["1", "2"])
 @pytest.mark.parametrize("S", [5, 20])
-def test_corr_volume_sh_stress_coordinates(S):
+def test_corr_volume_sh_stress_coordinates(S, version, monkeypatch):
     """Integer / half-integer / border / out-of-range coordinates (9-wide footprints, clamped taps), ragged frame
     chunks (S = 5: one short chunk; S = 20: 16 + 4) -- against the exact-f32 fused sampler (itself pinned to the goldens)."""
     from cotracker_amd import ops
+    monkeypatch.setenv("CTK_CORR", version)
     r = np.random.RandomState(S)
     H0, W0, N = 48, 64, 90
     f0 = torch.from_numpy(r.standard_normal((S, H0, W0, 128)).astype(np.float32)).to(dev())

@@ -16,9 +16,10 @@ import re
 import sys
 
 NAME_MAP = [
-    (r"gemm_sh_kernel<2, 2, 2, 2>", "gemm_sh_128x128"),
-    (r"gemm_sh_kernel<4, 2, 2, 2>", "gemm_sh_256x128"),
-    (r"gemm_sh_kernel<2, 2, 1, 1>", "gemm_sh_64x64"),
+    (r"gemm_sh_kernel<2, 2, 2, 2,", "gemm_sh_128x128"),
+    (r"gemm_sh_kernel<4, 2, 2, 2, 3", "gemm_sh_256x128x3"),
+    (r"gemm_sh_kernel<4, 2, 2, 2,", "gemm_sh_256x128"),
+    (r"gemm_sh_kernel<2, 2, 1, 1,", "gemm_sh_64x64"),
     (r"gemm_f16x3_kernel<2, 2>", "gemm_f16x3_128x128"),
     (r"gemm_f16x3_kernel<1, 1>", "gemm_f16x3_64x64"),
     (r"gemm_f32_kernel<2, 2>", "gemm_f32_128x128"),
