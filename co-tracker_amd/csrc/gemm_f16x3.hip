@@ -436,6 +436,7 @@ int launch_with_lds(K kernel, unsigned blocks, unsigned threads, size_t lds_byte
 }  // namespace
 
 int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
+
   const long blocks128 = (long)((g.M + 127) / 128) * (g.N / 128) * g.batch;
   const bool big = (g.N % 128) == 0 && blocks128 >= 384;
   if (g.a_split) {
