@@ -673,12 +673,14 @@ int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh
   const double units = (double)ncount * a->S * CTK_LEVELS;
   CtkProfScope ps("corr_volume_sh", units * 2.0 * 49 * 49 * 128,
                   units * (64.0 * 128 * 4 + 49.0 * 128 * 4 / a->S + 2.0 + 2401.0 * 4), s);
-  // Dev knob, read per call: CTK_CORR = 1 selects version 1 (workgroup per frame, LDS footprint + VALU blend)
+  // Dev knobs, read per call: CTK_CORR = 2 selects version 2 (wave per frame, register-fed footprint, MFMA blend);
+  // CTK_CORR_DBG = its bisection bits.  Measured on MI355X at the C3 window (tools/bench_corr.py): version 1
+  // 2.75 ms, version 2 3.0 ms per launch.
   const char* dbg = getenv("CTK_CORR_DBG");
   p.dbg = dbg ? atoi(dbg) : 0;
   const char* ver = getenv("CTK_CORR");
-  if (ver && atoi(ver) == 1) hipLaunchKernelGGL(corr_volume_sh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(corr_volume_sh2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  if (ver && atoi(ver) == 2) hipLaunchKernelGGL(corr_volume_sh2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(corr_volume_sh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }

@@ -36,11 +36,11 @@ __device__ __forceinline__ float ctk_gelu_erf(float x) {  // nn.GELU() (exact), 
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float ctk_gelu_tanh(float x) {  // nn.GELU(approximate="tanh"), blocks.py:418
-  const float k = 0.79788456080286535588f;
-  const float inner = k * (x + 0.044715f * x * x * x);
-  // tanh(u) = 1 - 2/(exp(2u)+1): v_exp_f32 based, abs error ~1e-7 (ocml tanhf costs ~40 VALU per value)
-  const float e = __expf(2.0f * inner);
-  return 0.5f * x * (2.0f - __fdividef(2.0f, e + 1.0f));
+  // 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3): 8 VALU with the raw v_exp_f32 /
+  // v_rcp_f32 (1 ulp each; exp -> inf or 0 at the extremes gives the exact limits -0 and x).  ocml tanhf costs ~40.
+  const float t = x * fmaf(x * x, 0.044715f, 1.0f);
+  const float e = __builtin_amdgcn_exp2f(t * -2.3022081986f);  // -2 sqrt(2/pi) log2(e)
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // ---------------------------------------------------------------------------------------

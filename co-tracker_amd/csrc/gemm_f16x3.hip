@@ -93,6 +93,79 @@ __device__ __forceinline__ void gemm_epilogue(const CtkGemmP& g, f32x16 (&acc)[M
   }
 }
 
+// ---- compile-time epilogues of the hot launches -----------------------------------------------------
+// For the 12-K-tile Linears of the transformer (K = 384) the epilogue, not the MFMA loop, is the bulk of a wave's
+// instruction stream (SQ counters, profiles/r01_gemm_sh_sq_counters.txt: fc1 issues ~2350 VALU per wave there vs
+// ~530 in its main loop), and an epilogue wave keeps its SIMD's MFMA pipe idle unless the co-resident workgroup is
+// in its main loop.  EPI encodes the flags as constants -- act (bits 0-1), residual (2), SH output (3), per-row
+// bias table (4), bias (5) -- so the runtime branches, the zero residual adds and the per-quad 64-bit addressing
+// of the generic epilogue disappear: two row base pointers per lane, every column offset an instruction immediate.
+constexpr int EPI_GENERIC = -1;
+constexpr int epi_code(int act, bool res, bool split, bool brows, bool bias) {
+  return act | (res ? 4 : 0) | (split ? 8 : 0) | (brows ? 16 : 0) | (bias ? 32 : 0);
+}
+
+template <int MR, int NR, int EPI>
+__device__ __forceinline__ void gemm_epilogue_c(const CtkGemmP& g, f32x16 (&acc)[MR][NR], const int m_base,
+                                                const int n_base, const int r32, const int half, const int bz) {
+  constexpr int ACT = EPI & 3;
+  constexpr bool RES = (EPI & 4) != 0, SPLIT = (EPI & 8) != 0, BROWS = (EPI & 16) != 0, BIAS = (EPI & 32) != 0;
+  const float unscale = reinterpret_cast<const float*>(g.Wp)[1];
+  const int c0 = n_base + half * 4;  // my first column; register quad (ni, q) adds ni*32 + q*8 (compile-time)
+  f32x4 bv[NR][4];
+  if (BIAS) {
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[ni][q] = *reinterpret_cast<const f32x4*>(g.bias + c0 + ni * 32 + q * 8);
+  }
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi) {
+    const int row = m_base + mi * 32 + r32;
+    const int rowc = min(row, g.M - 1);
+    const float* rp = RES ? g.resid + (long)bz * g.c_bs + (long)rowc * g.ldr + c0 : nullptr;
+    const float* bp = BROWS ? g.bias_rows + (long)(rowc % g.bias_period) * g.N + c0 : nullptr;
+    f32x4 rv[NR][4];
+    if (RES) {
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[ni][q] = *reinterpret_cast<const f32x4*>(rp + ni * 32 + q * 8);
+    }
+    float* cf = static_cast<float*>(g.C) + (long)bz * g.c_bs + (long)row * g.ldc + c0;
+    // SH row: column c sits at (c >> 5) * 64 + (c & 31) halves; n_base is a multiple of 32 and (c & 31) = q*8 + half*4
+    _Float16* ch = static_cast<_Float16*>(g.C) + (long)bz * g.c_bs + (long)row * g.ldc + (n_base >> 5) * 64 + half * 4;
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][q * 4 + e] * unscale;
+        if (BIAS) v += bv[ni][q];
+        if (BROWS) v += *reinterpret_cast<const f32x4*>(bp + ni * 32 + q * 8);
+        if (ACT == CTK_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_erf(v[e]);
+        } else if (ACT == CTK_ACT_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_tanh(v[e]);
+        }
+        if (RES) v += rv[ni][q];
+        if (row < g.M) {
+          if (SPLIT) {
+            f16x4 hi, lo;
+            ctk_split4(v, hi, lo);
+            *reinterpret_cast<f16x4*>(ch + ni * 64 + q * 8) = hi;
+            *reinterpret_cast<f16x4*>(ch + ni * 64 + q * 8 + 32) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(cf + ni * 32 + q * 8) = v;
+          }
+        }
+      }
+  }
+}
+
 template <int MR, int NR>
 __global__ __launch_bounds__(256) void gemm_f16x3_kernel(CtkGemmP g) {
   constexpr int BM = 64 * MR, BN = 64 * NR;
@@ -219,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(CtkGemmP g) {
 // NS = 3 (one workgroup per CU): tile kt+3 is requested there and has two tiles of MFMAs to land; the mid-tile
 // barrier is then a raw s_barrier behind a COUNTED s_waitcnt vmcnt (one tile stays in flight across it) --
 // __syncthreads() would drain the DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
-template <int WM, int WN, int MR, int NR, int NS>
+template <int WM, int WN, int MR, int NR, int NS, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
@@ -379,7 +452,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
     mma_term(fb, 2);
   }
 
-  gemm_epilogue<MR, NR>(g, acc, m0 + wm * 32 * MR, n0 + wn * 32 * NR, r32, half, bz);
+  if (EPI == EPI_GENERIC) gemm_epilogue<MR, NR>(g, acc, m0 + wm * 32 * MR, n0 + wn * 32 * NR, r32, half, bz);
+  else gemm_epilogue_c<MR, NR, EPI>(g, acc, m0 + wm * 32 * MR, n0 + wn * 32 * NR, r32, half, bz);
 }
 
 // ---- weight packing ------------------------------------------------------------------------
@@ -452,7 +526,22 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
     } else if (big) {
       g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;
       CtkProfScope ps("gemm_sh_128x128", flops, bytes, s);
-      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2, 2>), dim3((unsigned)blocks128), dim3(256), 0, s, g);
+      // the six flag combinations of the update path get compile-time epilogues; anything else the generic one
+      const int code = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
+      const dim3 grid((unsigned)blocks128), blk(256);
+#define CTK_SH128(E) hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2, 2, E>), grid, blk, 0, s, g)
+      const char* ge = getenv("CTK_GEMM_EPI");  // dev knob: CTK_GEMM_EPI=0 forces the generic epilogue
+      if (ge && atoi(ge) == 0) CTK_SH128(EPI_GENERIC);
+      else switch (code) {
+        case epi_code(CTK_ACT_GELU_ERF, false, true, false, true): CTK_SH128(epi_code(CTK_ACT_GELU_ERF, false, true, false, true)); break;    // corr_mlp.fc1
+        case epi_code(CTK_ACT_NONE, false, true, false, true): CTK_SH128(epi_code(CTK_ACT_NONE, false, true, false, true)); break;            // corr_mlp.fc2 -> x
+        case epi_code(CTK_ACT_NONE, false, false, true, false): CTK_SH128(epi_code(CTK_ACT_NONE, false, false, true, false)); break;          // input_transform (+ time bias rows)
+        case epi_code(CTK_ACT_NONE, false, false, false, true): CTK_SH128(epi_code(CTK_ACT_NONE, false, false, false, true)); break;          // to_q / to_kv
+        case epi_code(CTK_ACT_NONE, true, false, false, true): CTK_SH128(epi_code(CTK_ACT_NONE, true, false, false, true)); break;            // to_out / mlp.fc2 (+ residual)
+        case epi_code(CTK_ACT_GELU_TANH, false, true, false, true): CTK_SH128(epi_code(CTK_ACT_GELU_TANH, false, true, false, true)); break;  // mlp.fc1
+        default: CTK_SH128(EPI_GENERIC);
+      }
+#undef CTK_SH128
     } else {
       g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
       CtkProfScope ps("gemm_sh_64x64", flops, bytes, s);
