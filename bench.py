@@ -292,6 +292,8 @@ def main():
         traffic = {}
         if os.path.exists(args.pmc_traffic):
             traffic = json.load(open(args.pmc_traffic))
+            if traffic.pop("_workload", "c3_sliding") != args.workload:
+                traffic = {}  # the PMC passes were collected on another workload: per-launch bytes do not transfer
         if rows:
             result["roofline"] = roofline_entry(rows[0], traffic)
             for r in rows:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
 
-    pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [workload]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md, section HBM: FETCH_SIZE / WRITE_SIZE are in
 KiB; on gfx950 FETCH_SIZE reports one half of the bytes of wide (16 B/lane) coalesced reads -> doubled here;
@@ -27,8 +27,10 @@ NAME_MAP = [
     (r"corr_volume_sh_kernel", "corr_volume_sh"),
     (r"corr_volume_kernel", "corr_volume"),
     (r"attention_merge_kernel", "attention_merge"),
-    (r"attention_kernel", "attention"),
-    (r"attention_mfma", "attention"),
+    (r"attention_self_kernel", "attention_time"),
+    (r"attention_kv64_kernel", "attention_p2v"),   # also the (small) virtual self attention launches
+    (r"attention_q64_kernel", "attention_v2p"),
+    (r"attention_kernel", "attention_valu"),
     (r"layernorm_kernel", "layernorm"),
     (r"assemble_kernel", "assemble_tokens"),
     (r"heads_kernel", "heads_update"),
@@ -59,6 +61,7 @@ def collect(path, counter):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "c3_sliding"  # bench.py workload the passes were collected on
     fetch = collect(fetch_csv, "FETCH_SIZE")
     write = collect(write_csv, "WRITE_SIZE")
     res = {}
@@ -70,7 +73,9 @@ def main():
                   "dispatches": fetch[k][1] if k in fetch else write[k][1],
                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950), KiB -> B"}
     lib_names = {nm for _, nm in NAME_MAP}
-    json.dump({k: v for k, v in res.items() if k in lib_names}, open(out, "w"), indent=1)  # library kernels only (others are printed)
+    keep = {k: v for k, v in res.items() if k in lib_names}
+    keep["_workload"] = workload  # bench.py attaches `traffic` only to this workload's roofline
+    json.dump(keep, open(out, "w"), indent=1)  # library kernels only (others are printed)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:28s} n={v['dispatches']:6d}  fetch {v['fetch_bytes_per_launch'] or 0:14.0f} B  write {v['write_bytes_per_launch'] or 0:14.0f} B")
 
