@@ -55,6 +55,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="c4_online: direct launches instead of the captured hipGraph")
     ap.add_argument("--pmc-traffic", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-kernel HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
+                         "multi-rank path on a box with fewer GPUs than ranks, together with --single-device)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="dev/test: every rank uses cuda:0 (rank-sharded code path on a 1-GPU box; numbers are meaningless)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="Linear back end: split-half MFMA (3 f16 MFMAs per product, fp32-class accuracy) or exact-f32 MFMA")
     return ap.parse_args()
@@ -176,11 +181,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from cotracker_amd import model as ctk_model
     from cotracker_amd import ops
