@@ -34,7 +34,9 @@ struct AttnP {
   int o_split; // out is SH halves (o_ld = halves per row)
   int bpw;     // batches per wave (n1 < 64) or 1
   int qtiles;  // ceil(n1/64) when n1 >= 64
-  float scale;
+  float scale;   // 48^-0.5
+  float scale2;  // 48^-0.5 * log2(e): the MFMA kernels keep scores in the log2 domain (raw v_exp_f32, no multiply)
+  int log2m;     // partial maxima are in the log2 domain (attention_q64_kernel) -> the merge uses exp2
 };
 
 __global__ __launch_bounds__(64) void attention_kernel(AttnP p) {
@@ -209,20 +211,30 @@ __global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
       vimg[64 * VP + (d4 * 4 + e) * VP + pos] = lo[e];
     }
   }
+
+  // raw Q rows of a 32-query tile (6 float4 per lane); the next tile's are requested before this tile's MFMAs
+  f32x4 qraw[6];
+  auto load_q = [&](int q0) {
+    const int qi = min(q0 + r32, p.n1 - 1);
+    const float* qp = p.q + ((long)b * p.q_bs + (long)qi * p.q_is) * p.q_ld + head * HD + half * 8;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      qraw[2 * j] = *reinterpret_cast<const f32x4*>(qp + 16 * j);
+      qraw[2 * j + 1] = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4);
+    }
+  };
+  const int q_first = blockIdx.x * QT_PER_WG * 128 + wave * 32;
+  if (q_first < p.n1) load_q(q_first);
   __syncthreads();
 
   for (int qt = 0; qt < QT_PER_WG; ++qt) {
-    const int q0 = (blockIdx.x * QT_PER_WG + qt) * 128 + wave * 32;
+    const int q0 = q_first + qt * 128;
     if (q0 >= p.n1) break;  // wave-uniform
     const int qi = min(q0 + r32, p.n1 - 1);
-    const float* qp = p.q + ((long)b * p.q_bs + (long)qi * p.q_is) * p.q_ld + head * HD + half * 8;
     f16x8 qh[3], ql[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale;
-      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale;
-      ctk_split8(a, c, qh[j], ql[j]);
-    }
+    for (int j = 0; j < 3; ++j) ctk_split8(qraw[2 * j] * p.scale2, qraw[2 * j + 1] * p.scale2, qh[j], ql[j]);
+    if (qt + 1 < QT_PER_WG && q0 + 128 < p.n1) load_q(q0 + 128);
     // S'[key][query]
     f32x16 sacc[2];
 #pragma unroll
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = expf(sacc[kt][e] - mx);
+        const float pv = __builtin_amdgcn_exp2f(sacc[kt][e] - mx);
         sum += pv;
         sacc[kt][e] = pv * PSCALE;
       }
@@ -317,8 +329,8 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
     const float* qp = p.q + ((long)b * p.q_bs + (long)(qt * 32 + r32) * p.q_is) * p.q_ld + head * HD + half * 8;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale;
-      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale2;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale2;
       ctk_split8(a, c, qh[qt][j], ql[qt][j]);
     }
   }
@@ -402,12 +414,12 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
       for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[qt][e]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float mnew = fmaxf(m[qt], tmax);       // finite: every tile holds at least one valid key
-      const float alpha = expf(m[qt] - mnew);      // m = -inf on the first tile -> 0
+      const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);      // m = -inf on the first tile -> 0
       m[qt] = mnew;
       float psum = 0.0f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = expf(sacc[qt][e] - mnew);
+        const float pv = __builtin_amdgcn_exp2f(sacc[qt][e] - mnew);
         psum += pv;
         sacc[qt][e] = pv * PSCALE;
       }
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float wm = red[w][qi][0];
-      const float wgt = (wm == -INFINITY) ? 0.0f : expf(wm - mm);  // waves that saw no tile carry m = -inf, l = 0
+      const float wgt = (wm == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(wm - mm);  // waves that saw no tile carry m = -inf, l = 0
       L += wgt * red[w][qi][1];
 #pragma unroll
       for (int d = 0; d < 12; ++d) o[d] += wgt * red[w][qi][2 + part * 12 + d];
@@ -523,8 +535,8 @@ __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
     const float* qp = p.q + ((long)qbc * p.q_bs + (long)qic * p.q_is) * p.q_ld + head * HD + half * 8;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale;
-      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * j) * p.scale2;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4) * p.scale2;
       ctk_split8(a, c, qh[j], ql[j]);
     }
   }
@@ -576,12 +588,12 @@ __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     float mnew = fmaxf(m, tmax);
     if (mnew == -INFINITY) mnew = 0.0f;  // a query slot with no valid key (padding slot): all probabilities 0, never stored
-    const float alpha = expf(m - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
     m = mnew;
     float psum = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = expf(sacc[e] - mnew);
+      const float pv = __builtin_amdgcn_exp2f(sacc[e] - mnew);
       psum += pv;
       sacc[e] = pv * PSCALE;
     }
@@ -641,7 +653,7 @@ __global__ void attention_merge_kernel(AttnP p) {
   for (int s = 0; s < p.splits; ++s) m = fmaxf(m, base[s * stride]);
   float l = 0.0f, a = 0.0f;
   for (int s = 0; s < p.splits; ++s) {
-    const float w = expf(base[s * stride] - m);
+    const float w = p.log2m ? __builtin_amdgcn_exp2f(base[s * stride] - m) : expf(base[s * stride] - m);
     l += w * base[s * stride + 1];
     a += w * base[s * stride + 2 + d];
   }
@@ -681,6 +693,8 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
   if (p.splits > 1 && !a->partial) return CTK_E_NULL;
   p.partial = a->partial;
   p.scale = 0.14433756729740643f;  // 48 ** -0.5 (blocks.py:372)
+  p.scale2 = 0.14433756729740643f * 1.4426950408889634f;
+  p.log2m = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const double flops = 4.0 * a->nbatch * (double)a->n1 * a->n2 * CTK_HID;
   const double bytes = 4.0 * a->nbatch * ((double)a->n1 * 2 + (double)a->n2 * 2) * CTK_HID;
@@ -704,6 +718,7 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
     p.splits = (a->n2 + p.keys_per_split - 1) / p.keys_per_split;  // drop empty splits
     p.bpw = 1;
     p.qtiles = 1;
+    p.log2m = 1;
     CtkProfScope ps("attention_v2p", flops, bytes, s);
     hipLaunchKernelGGL(attention_q64_kernel, dim3((unsigned)p.splits, CTK_HEADS, (unsigned)a->nbatch), dim3(256), 0, s, p);
     CTK_HIP_CHECK_LAUNCH();
