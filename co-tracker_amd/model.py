@@ -75,13 +75,16 @@ class _CrossBlock(nn.Module):  # cotracker.py:534-557
 
 
 class _UpdateFormerParams(nn.Module):  # cotracker.py:387-462
-    def __init__(self, input_dim=1110, hidden=384, depth=3, num_virtual_tracks=64):
+    def __init__(self, input_dim=1110, hidden=384, depth=3, num_virtual_tracks=64, flow_out=2, vis_conf_head=True):
+        """CoTracker3: flow_head(2) + vis_conf_head(2) (linear_layer_for_vis_conf=True); CoTracker2: one flow_head of
+        output_dim = 130 and no vis_conf_head (cotracker.py:413-417)."""
         super().__init__()
         self.input_transform = _Lin(input_dim, hidden)
-        self.flow_head = _Lin(hidden, 2)
-        self.vis_conf_head = _Lin(hidden, 2)
+        self.flow_head = _Lin(hidden, flow_out)
         nn.init.trunc_normal_(self.flow_head.weight, std=0.001)
-        nn.init.trunc_normal_(self.vis_conf_head.weight, std=0.001)
+        if vis_conf_head:
+            self.vis_conf_head = _Lin(hidden, 2)
+            nn.init.trunc_normal_(self.vis_conf_head.weight, std=0.001)
         self.virual_tracks = nn.Parameter(torch.randn(1, num_virtual_tracks, 1, hidden))  # (sic) reference key
         self.time_blocks = nn.ModuleList([_AttnBlock(hidden) for _ in range(depth)])
         self.space_virtual_blocks = nn.ModuleList([_AttnBlock(hidden) for _ in range(depth)])

@@ -39,6 +39,8 @@ def synthetic_tensor(name: str, shape, seed: int = 0, head_scale: float = 8.0) -
         else:
             a = np.sqrt(6.0 / (shape[0] + shape[1]))
             v = r.uniform(-a, a, size=shape)
+    elif name.endswith(".weight") and len(shape) == 1:  # affine norm scale (CoTracker2's GroupNorm, cotracker.py:79)
+        v = 1.0 + 0.1 * r.standard_normal(shape)
     elif name.endswith(".bias"):
         v = r.standard_normal(shape) * (0.01 if is_head else 0.02)
     else:
@@ -51,7 +53,7 @@ def fill_synthetic_(module: torch.nn.Module, seed: int = 0, head_scale: float = 
     """In-place synthetic checkpoint for any module with the CoTracker3 key set."""
     sd = module.state_dict()
     for name, t in sd.items():
-        if name == "time_emb":  # deterministic buffer (embeddings.py:59-84), keep
+        if name in ("time_emb", "pos_emb"):  # deterministic buffers (embeddings.py:11-84), keep
             continue
         t.copy_(synthetic_tensor(name, t.shape, seed, head_scale).to(t.device, t.dtype))
     inval = getattr(module, "invalidate_packed_weights", None)

@@ -289,8 +289,9 @@ def mlp(x, p, prefix, act):
 # --------------------------------------------------------------------------
 # a-8a  Attention                        blocks.py:379-398
 # --------------------------------------------------------------------------
-def attention(x, context, p, prefix, heads=8):
-    """x [B,N1,C], context [B,N2,C]; k = first half of to_kv, v = second half."""
+def attention(x, context, p, prefix, heads=8, attn_bias=None):
+    """x [B,N1,C], context [B,N2,C]; k = first half of to_kv, v = second half.
+    attn_bias (broadcastable to [B,heads,N1,N2]) is added to the scaled logits (blocks.py:392-394)."""
     B, N1, C = x.shape
     N2 = context.shape[1]
     hd = C // heads
@@ -301,6 +302,8 @@ def attention(x, context, p, prefix, heads=8):
     k = k.reshape(B, N2, heads, hd).transpose(0, 2, 1, 3)
     v = v.reshape(B, N2, heads, hd).transpose(0, 2, 1, 3)
     sim = (q @ k.transpose(0, 1, 3, 2)).astype(f32) * f32(48 ** -0.5)  # blocks.py:372
+    if attn_bias is not None:
+        sim = (sim + np.asarray(attn_bias, dtype=f32)).astype(f32)
     sim = sim - sim.max(axis=-1, keepdims=True)
     e = np.exp(sim).astype(f32)
     attn = (e / e.sum(axis=-1, keepdims=True)).astype(f32)
@@ -316,11 +319,21 @@ def attn_block(x, p, prefix):
     return x
 
 
-def cross_attn_block(x, context, p, prefix):
-    """CrossAttnBlock.forward, cotracker.py:559-577 (mask=None)."""
+def cross_attn_block(x, context, p, prefix, mask=None):
+    """CrossAttnBlock.forward, cotracker.py:559-577.  mask [B, n] bool (CoTracker2 only): when n equals the number
+    of queries it masks QUERIES (every logit of a masked query gets -FLT_MAX, i.e. that query attends uniformly),
+    otherwise KEYS (:560-572)."""
     ctx = layer_norm(context, p[prefix + "norm_context.weight"],
                      p[prefix + "norm_context.bias"], eps=1e-5)  # cotracker.py:540
-    x = (x + attention(layer_norm(x, eps=1e-6), ctx, p, prefix + "cross_attn.")).astype(f32)
+    bias = None
+    if mask is not None:
+        mask = np.asarray(mask, dtype=bool)
+        neg = -np.finfo(np.float32).max
+        if mask.shape[1] == x.shape[1]:
+            bias = ((~mask)[:, None, :, None] * f32(neg)).astype(f32)
+        else:
+            bias = ((~mask)[:, None, None, :] * f32(neg)).astype(f32)
+    x = (x + attention(layer_norm(x, eps=1e-6), ctx, p, prefix + "cross_attn.", attn_bias=bias)).astype(f32)
     x = (x + mlp(layer_norm(x, eps=1e-6), p, prefix + "mlp.", gelu_tanh)).astype(f32)
     return x
 
@@ -328,8 +341,9 @@ def cross_attn_block(x, context, p, prefix):
 # --------------------------------------------------------------------------
 # a-8  EfficientUpdateFormer.forward     cotracker.py:483-531
 # --------------------------------------------------------------------------
-def update_former(x, p, prefix="updateformer.", num_virtual=64, depth=3):
-    """x [B,N,T,1110] -> delta [B,N,T,4]."""
+def update_former(x, p, prefix="updateformer.", num_virtual=64, depth=3, mask=None):
+    """x [B,N,T,input_dim] -> delta [B,N,T,out].  CoTracker3: depth 3, flow_head(2) ++ vis_conf_head(2), no mask.
+    CoTracker2 (cotracker.py:46-56): depth 6, one flow_head of 130 outputs, mask [B*T, N] (attention_mask)."""
     x = np.asarray(x, dtype=f32)
     tokens = linear(x, p[prefix + "input_transform.weight"], p[prefix + "input_transform.bias"])
     B, _, T, C = tokens.shape
@@ -341,13 +355,15 @@ def update_former(x, p, prefix="updateformer.", num_virtual=64, depth=3):
         tokens = tt.reshape(B, N, T, C)
         st = np.ascontiguousarray(tokens.transpose(0, 2, 1, 3)).reshape(B * T, N, C)
         pt, vt = st[:, : N - num_virtual], st[:, N - num_virtual:]
-        vt = cross_attn_block(vt, pt, p, f"{prefix}space_virtual2point_blocks.{i}.")
+        vt = cross_attn_block(vt, pt, p, f"{prefix}space_virtual2point_blocks.{i}.", mask)
         vt = attn_block(vt, p, f"{prefix}space_virtual_blocks.{i}.")
-        pt = cross_attn_block(pt, vt, p, f"{prefix}space_point2virtual_blocks.{i}.")
+        pt = cross_attn_block(pt, vt, p, f"{prefix}space_point2virtual_blocks.{i}.", mask)
         st = np.concatenate([pt, vt], axis=1)
         tokens = st.reshape(B, T, N, C).transpose(0, 2, 1, 3)
     tokens = tokens[:, : N - num_virtual]
     flow = linear(tokens, p[prefix + "flow_head.weight"], p[prefix + "flow_head.bias"])
+    if prefix + "vis_conf_head.weight" not in p:  # linear_layer_for_vis_conf=False (CoTracker2)
+        return flow.astype(f32)
     vc = linear(tokens, p[prefix + "vis_conf_head.weight"], p[prefix + "vis_conf_head.bias"])
     return np.concatenate([flow, vc], axis=-1).astype(f32)
 
@@ -587,3 +603,143 @@ def model_forward_offline(fmaps, queries, p, iters=4, stride=4, model_resolution
     c, v, f = forward_window(pyr, coords, support, vis, conf, p, iters=iters,
                              model_resolution=model_resolution, stride=stride)
     return (c * f32(stride)).astype(f32), sigmoid(v[..., 0]), sigmoid(f[..., 0])
+
+
+# ==========================================================================
+# CoTracker2 (cotracker.py:29-384) -- SURVEY section 8(f) rank 3: the model around CorrBlock
+# ==========================================================================
+def get_2d_embedding(xy, C=64, cat_coords=True):
+    """embeddings.py:87-120: [.., 2] -> [.., 2 (coords) + C (x: sin/cos interleaved) + C (y)]."""
+    xy = np.asarray(xy, dtype=f32)
+    div = (np.arange(0, C, 2, dtype=f32) * f32(1000.0 / C)).astype(f32)
+    out = []
+    for a in (xy[..., 0:1], xy[..., 1:2]):
+        arg = (a * div).astype(f32)
+        pe = np.zeros(xy.shape[:-1] + (C,), dtype=f32)
+        pe[..., 0::2] = np.sin(arg)
+        pe[..., 1::2] = np.cos(arg)
+        out.append(pe)
+    pe = np.concatenate(out, axis=-1)
+    return np.concatenate([xy, pe], axis=-1).astype(f32) if cat_coords else pe
+
+
+def sample_features4d(inp, coords):
+    """model_utils.py:258-290: input [B,C,H,W], coords [B,R,2]=(x,y) -> [B,R,C] (4-D grid_sample path)."""
+    out = bilinear_sampler_4d(inp, np.asarray(coords, dtype=f32)[:, :, None, :])  # [B,C,R,1]
+    return np.ascontiguousarray(out[..., 0].transpose(0, 2, 1))
+
+
+def group_norm1(x, weight, bias, eps=1e-5):
+    """nn.GroupNorm(1, C) on a 2-D [rows, C] input (cotracker.py:79, used at :167): one group = the whole row."""
+    return layer_norm(x, weight, bias, eps=eps)
+
+
+def forward_window_v2(fmaps, coords, track_feat, vis, track_mask, attention_mask, p, iters=4, stride=4, trace=None):
+    """CoTracker2.forward_window (cotracker.py:86-173).  fmaps [B,S,C,H,W] (NOT normalised), coords [B,S,N,2]
+    feature units, track_feat [B,S,N,C], vis [B,S,N,1], track_mask [B,S_init,N,1], attention_mask [B,S,N] bool.
+    Returns (coords of the last iteration in feature units [B,S,N,2], vis logits [B,S,N])."""
+    fmaps = np.asarray(fmaps, dtype=f32)
+    coords = np.asarray(coords, dtype=f32)
+    track_feat = np.asarray(track_feat, dtype=f32)
+    B, S = fmaps.shape[:2]
+    N = coords.shape[2]
+    C = track_feat.shape[-1]
+    tm = np.asarray(track_mask, dtype=f32)
+    if tm.shape[1] < S:
+        tm = np.concatenate([tm, np.zeros((B, S - tm.shape[1], N, 1), f32)], axis=1)
+    tmv = np.concatenate([tm, np.asarray(vis, dtype=f32)], axis=-1).transpose(0, 2, 1, 3).reshape(B * N, S, 2)
+    pyr = corrblock_pyramid(fmaps)
+    pos = sample_features4d(np.repeat(np.asarray(p["pos_emb"], dtype=f32), B, axis=0), coords[:, 0])  # [B,N,E]
+    pos = pos.reshape(B * N, 1, -1)
+    amask = np.asarray(attention_mask, dtype=bool).reshape(B * S, N)
+    for _ in range(iters):
+        fcorrs = corrblock_sample(corrblock_corr(pyr, track_feat), coords)  # [(B N), S, 196]
+        flows = (coords - coords[:, 0:1]).astype(f32).transpose(0, 2, 1, 3).reshape(B * N, S, 2)
+        flow_emb = get_2d_embedding(flows, 64, cat_coords=True)
+        tf_ = track_feat.transpose(0, 2, 1, 3).reshape(B * N, S, C)
+        x = np.concatenate([flow_emb, fcorrs, tf_, tmv], axis=2).astype(f32)
+        x = ((x + pos).astype(f32) + np.asarray(p["time_emb"], dtype=f32)).astype(f32)
+        delta = update_former(x.reshape(B, N, S, -1), p, depth=6, mask=amask)  # [B,N,S,130]
+        coords = (coords + delta[..., :2].transpose(0, 2, 1, 3)).astype(f32)
+        dfe = delta[..., 2:].reshape(B * N * S, C)
+        upd = gelu_erf(linear(group_norm1(dfe, p["norm.weight"], p["norm.bias"]),
+                              p["track_feat_updater.0.weight"], p["track_feat_updater.0.bias"]))
+        tfn = (upd + track_feat.transpose(0, 2, 1, 3).reshape(B * N * S, C)).astype(f32)
+        track_feat = np.ascontiguousarray(tfn.reshape(B, N, S, C).transpose(0, 2, 1, 3))
+        if trace is not None:
+            trace.append(dict(x=x, delta=delta, coords=coords.copy(), track_feat=track_feat.copy()))
+    vis_pred = linear(track_feat, p["vis_predictor.0.weight"], p["vis_predictor.0.bias"]).reshape(B, S, N)
+    return coords, vis_pred
+
+
+class OnlineStateV2:
+    """cotracker.py:187-191"""
+
+    def __init__(self):
+        self.online_ind = 0
+        self.track_feat = None
+        self.coords = None
+        self.vis = None
+
+
+def model_forward_v2(fmaps, queries, p, window_len=8, iters=4, stride=4, is_online=False, state=None, T=None):
+    """CoTracker2.forward after fnet (cotracker.py:193-384).  fmaps [B,T_pad,C,H4,W4] already padded to the window
+    multiple (the reference pads the video with its last frame; fnet is per-frame).  queries [B,N,3]=(t,x,y) px.
+    Returns coords [B,T,N,2] px, vis [B,T,N] (post-sigmoid)."""
+    fmaps = np.asarray(fmaps, dtype=f32)
+    queries = np.asarray(queries, dtype=f32)
+    B, T_pad = fmaps.shape[:2]
+    T = T_pad if T is None else T
+    N = queries.shape[1]
+    S = window_len
+    step = S // 2
+    qf = queries[:, :, 0].astype(np.int64)
+    qc = (queries[..., 1:3] / f32(stride)).astype(f32)
+    coords_pred = np.zeros((B, T, N, 2), dtype=f32)
+    vis_pred = np.zeros((B, T, N), dtype=f32)
+    if is_online and state.coords is not None:
+        pad = min(step, T - step)
+        coords_pred = np.concatenate([state.coords, np.zeros((B, pad, N, 2), f32)], axis=1)
+        vis_pred = np.concatenate([state.vis, np.zeros((B, pad, N), f32)], axis=1)
+    frames = qf - state.online_ind if is_online else qf
+    # get_track_feat (cotracker.py:175-185): trilinear sample at (t, x, y), one vector per track, repeated over S
+    sc = np.concatenate([frames[:, None, :, None].astype(f32), qc[:, None]], axis=-1)  # [B,1,N,3]
+    tf0 = sample_features5d(fmaps, sc)  # [B,1,N,C]
+    track_feat = np.repeat(tf0, S, axis=1).astype(f32)
+    if is_online:
+        left = 0 if state.online_ind == 0 else state.online_ind + step
+        right = state.online_ind + S
+        smask = ((qf >= left) & (qf < right))[:, None, :, None]
+        if state.track_feat is None:
+            state.track_feat = np.zeros_like(track_feat)
+        state.track_feat = (state.track_feat + track_feat * smask).astype(f32)
+        track_feat = state.track_feat.copy()
+    num_windows = (T - S + step - 1) // step + 1
+    indices = [state.online_ind] if is_online else list(range(0, step * num_windows, step))
+    coords_init = np.broadcast_to(qc.reshape(B, 1, N, 2), (B, S, N, 2)).astype(f32)
+    vis_init = np.full((B, S, N, 1), 10.0, dtype=f32)
+    for ind in indices:
+        overlap = S - step
+        if ind > 0:
+            copy_over = (qf < ind + overlap)[:, None, :, None]
+            cprev = coords_pred[:, ind: ind + overlap] / f32(stride)
+            cprev = np.concatenate([cprev, np.repeat(cprev[:, -1:], step, axis=1)], axis=1)
+            vprev = vis_pred[:, ind: ind + overlap, :, None]
+            vprev = np.concatenate([vprev, np.repeat(vprev[:, -1:], step, axis=1)], axis=1)
+            coords_init = np.where(copy_over, cprev, coords_init).astype(f32)
+            vis_init = np.where(copy_over, vprev, vis_init).astype(f32)
+        amask = np.repeat((qf < ind + S)[:, None, :], S, axis=1)  # [B,S,N]
+        tmask = (qf[:, None, :, None] <= np.arange(ind, ind + S)[None, :, None, None])  # [B,S,N,1]
+        if ind > 0:
+            tmask = tmask.copy()
+            tmask[:, :overlap] = False
+        win = fmaps if is_online else fmaps[:, ind: ind + S]
+        c, v = forward_window_v2(win, coords_init, (amask[..., None] * track_feat).astype(f32), vis_init, tmask, amask,
+                                 p, iters=iters, stride=stride)
+        S_trim = T if is_online else min(T - ind, S)
+        coords_pred[:, ind: ind + S] = (c * f32(stride))[:, :S_trim]
+        vis_pred[:, ind: ind + S] = v[:, :S_trim]
+    if is_online:
+        state.online_ind += step
+        state.coords, state.vis = coords_pred, vis_pred
+    return coords_pred, sigmoid(vis_pred)

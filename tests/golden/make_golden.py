@@ -24,6 +24,7 @@ from cotracker.models.core.model_utils import bilinear_sampler  # noqa: E402
 from cotracker.models.core.cotracker.cotracker3_online import CoTrackerThreeOnline, posenc  # noqa: E402
 from cotracker.models.core.cotracker.cotracker3_offline import CoTrackerThreeOffline  # noqa: E402
 from cotracker.models.core.cotracker.blocks import CorrBlock  # noqa: E402
+from cotracker.models.core.cotracker.cotracker import CoTracker2  # noqa: E402
 from cotracker.predictor import CoTrackerPredictor, CoTrackerOnlinePredictor  # noqa: E402
 
 from cotracker_amd.weights import fill_synthetic_  # noqa: E402
@@ -225,6 +226,53 @@ def gen_corrblock():
     save("corrblock.npz", **out)
 
 
+@torch.no_grad()
+def gen_cotracker2():
+    """CoTracker2 (cotracker.py:29-384): update former with masks, forward_window, sliding and streaming forwards."""
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(41)
+    out = {}
+    torch.manual_seed(0)
+    m = CoTracker2(stride=4, window_len=8, model_resolution=(H, W)).eval()
+    # head_scale 1 (not the CoTracker3 "stress" 8): CoTracker2 feeds the updated track feature back into the
+    # correlation, so large per-iteration moves make the map chaotic (fp32 noise grows ~40x per iteration at 8)
+    fill_synthetic_(m, seed=6, head_scale=1.0)
+    # (i) update former alone: B=1, N=10 (3 masked), S=8, input 456, attention mask per (frame, point)
+    B, N, S = 1, 10, 8
+    x = torch.randn(B, N, S, 456, generator=g)
+    mask = torch.ones(B * S, N, dtype=torch.bool)
+    mask[:, 7:] = False
+    out.update(uf_x=x, uf_mask=mask, uf_delta=m.updateformer(x, mask))
+    # (ii) forward_window: 3 iterations on random (unnormalised) feature maps
+    fm = torch.nn.functional.interpolate(torch.randn(B * S, 128, H // 16, W // 16, generator=g), size=(H // 4, W // 4),
+                                         mode="bilinear", align_corners=True).reshape(B, S, 128, H // 4, W // 4)  # smooth
+    qc = torch.rand(B, N, 2, generator=g) * torch.tensor([W / 4 - 1.0, H / 4 - 1.0])
+    qc[:, :2] = qc[:, :2].round()
+    coords = qc[:, None].expand(B, S, N, 2) + 0.3 * torch.randn(B, S, N, 2, generator=g)
+    tf = torch.randn(B, 1, N, 128, generator=g).repeat(1, S, 1, 1)
+    amask = mask.reshape(B, S, N)
+    vis = torch.ones(B, S, N, 1) * 10
+    tmask = torch.ones(B, S, N, 1, dtype=torch.bool)
+    tmask[:, :3, 2:5] = False
+    cps, vp = m.forward_window(fmaps=fm, coords=coords.clone(), track_feat=amask.unsqueeze(-1) * tf, vis=vis,
+                               track_mask=tmask, attention_mask=amask, iters=3)
+    out.update(fw_fmaps=fm, fw_coords=coords, fw_track_feat=tf, fw_vis=vis, fw_track_mask=tmask, fw_attention_mask=amask,
+               fw_out_coords=cps[-1], fw_out_vis=vp)
+    # (iii) full forwards incl. encoder: sliding windows (T=20 -> 5 windows) and streaming.  ONE iteration per window:
+    # with random weights the 6+6-layer CoTracker2 iteration is chaotic -- the reference itself differs by 0.32 px
+    # between 1 and 8 CPU threads after 4 iterations (6e-5 px after 1) -- so only single iterations can be pinned.
+    video = synthetic_video(20, H, W, seed=4321)
+    q = _queries(g, 9, 14, H, W)
+    c, v, _ = m(video, q, iters=1)
+    out.update(video=video, queries=q, coords=c, vis=v)
+    m.init_video_online_processing()
+    for ind in range(0, video.shape[1] - 4, 4):
+        cs, vs, _ = m(video[:, ind:ind + 8], q, iters=1, is_online=True)
+    out.update(stream_coords=cs, stream_vis=vs)
+    out["fmaps"] = m.fnet(2 * (video[0] / 255.0) - 1.0)[None]
+    save("cotracker2.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_sampler()
@@ -232,3 +280,4 @@ if __name__ == "__main__":
     gen_models()
     gen_predictors()
     gen_corrblock()
+    gen_cotracker2()

@@ -177,3 +177,54 @@ def test_corrblock_oracle(golden):
     assert np.array_equal(out, g["cb_out"])
     out = O.corrblock_sample(corrs, g["cb_coords"])
     assert np.abs(out - g["cb_out"]).max() < 2e-6
+
+
+# ------------------------------------------------------------------------------------------
+# CoTracker2: oracle vs goldens of the unmodified reference (tests/golden/cotracker2.npz)
+# ------------------------------------------------------------------------------------------
+def _v2_params():
+    from cotracker_amd.model_v2 import CoTracker2
+    from cotracker_amd.weights import fill_synthetic_
+    m = CoTracker2(window_len=8, stride=4, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=6, head_scale=1.0)
+    return {k: v.numpy() for k, v in m.state_dict().items() if not k.startswith("fnet.")}
+
+
+def _logit(p):
+    p = np.asarray(p, np.float64)
+    return np.log(p / (1 - p))
+
+
+def test_cotracker2_update_former_with_masks():
+    g = np.load("tests/golden/cotracker2.npz")
+    p = _v2_params()
+    delta = O.update_former(g["uf_x"], p, depth=6, mask=g["uf_mask"])
+    assert delta.shape == g["uf_delta"].shape == (1, 10, 8, 130)
+    assert np.abs(delta - g["uf_delta"]).max() < 3e-5
+
+
+def test_cotracker2_forward_window():
+    g = np.load("tests/golden/cotracker2.npz")
+    p = _v2_params()
+    amask = g["fw_attention_mask"]
+    c, v = O.forward_window_v2(g["fw_fmaps"], g["fw_coords"], amask[..., None] * g["fw_track_feat"], g["fw_vis"],
+                               g["fw_track_mask"], amask, p, iters=3)
+    assert np.abs(c * 4.0 - g["fw_out_coords"]).max() < 1e-3
+    assert np.abs(v - g["fw_out_vis"]).max() < 3e-4  # logits of magnitude ~4 read off the 3x-updated track features
+
+
+def test_cotracker2_model_sliding_and_streaming():
+    g = np.load("tests/golden/cotracker2.npz")
+    p = _v2_params()
+    fm = g["fmaps"]                                   # [1,20,128,16,24] from the reference's fnet
+    T = fm.shape[1]
+    pad = (8 - T % 8) % 8
+    fmp = np.concatenate([fm, np.repeat(fm[:, -1:], pad, axis=1)], axis=1)
+    c, v = O.model_forward_v2(fmp, g["queries"], p, window_len=8, iters=1, T=T)  # goldens: 1 iteration per window
+    assert np.abs(c - g["coords"]).max() < 1e-3
+    assert np.abs(_logit(v) - _logit(g["vis"])).max() < 2e-4
+    st = O.OnlineStateV2()
+    for ind in range(0, T - 4, 4):
+        cs, vs = O.model_forward_v2(fm[:, ind:ind + 8], g["queries"], p, window_len=8, iters=1, is_online=True, state=st)
+    assert np.abs(cs - g["stream_coords"]).max() < 1e-3
+    assert np.abs(_logit(vs) - _logit(g["stream_vis"])).max() < 2e-4
