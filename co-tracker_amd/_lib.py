@@ -19,7 +19,7 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -73,6 +73,18 @@ class AttnArgs(C.Structure):
         ("out", _fp), ("o_ld", C.c_int64), ("o_bs", C.c_int64), ("o_is", C.c_int64),
         ("nbatch", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
         ("splits", C.c_int32), ("partial", _fp), ("o_split", C.c_int32),
+        ("key_mask", _fp), ("query_mask", _fp),
+    ]
+
+
+class FormerWeights(C.Structure):
+    """ctk_former_weights: the general update former (CoTracker2)."""
+    _fields_ = [
+        ("depth", C.c_int32), ("in_dim", C.c_int32), ("in_ld", C.c_int32), ("out_dim", C.c_int32), ("out_ld", C.c_int32),
+        ("in_w", _fp), ("in_p", _fp), ("in_b", _fp), ("in_bias_t", _fp), ("virtual_tokens", _fp),
+        ("head_w", _fp), ("head_p", _fp), ("head_b", _fp),
+        ("time_blocks", C.POINTER(BlockWeights)), ("virtual2point", C.POINTER(BlockWeights)),
+        ("virtual_self", C.POINTER(BlockWeights)), ("point2virtual", C.POINTER(BlockWeights)),
     ]
 
 
@@ -100,6 +112,11 @@ SYMBOLS = {
     "ctk_assemble_tokens": (C.c_int, [_P(WindowArgs), _fp, C.c_int32, _fp]),
     "ctk_update_former_workspace_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
     "ctk_update_former": (C.c_int, [C.c_int32, C.c_int32, _fp, _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
+    "ctk_update_former_ex": (C.c_int, [C.c_int32, C.c_int32, _fp, C.c_int32, _P(FormerWeights), _fp, _fp, _fp, C.c_size_t, _fp]),
+    "ctk_v2_assemble": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int32, _fp, C.c_int32, _fp]),
+    "ctk_v2_apply_delta": (C.c_int, [C.c_int32, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, C.c_float, _fp, _fp]),
+    "ctk_v2_vis_head": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp]),
+    "ctk_sample_features4d": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp, _fp]),
     "ctk_tap_indices": (C.c_int, [_P(WindowArgs), _fp, _fp]),
     "ctk_sample_patches": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_sample_support": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, _fp, _fp]),

@@ -2,15 +2,15 @@
 import torch
 
 from .model import CoTrackerThreeOffline, CoTrackerThreeOnline
+from .model_v2 import CoTracker2
 
 
 def build_cotracker(checkpoint=None, offline=True, window_len=16, v2=False):
     if v2:
-        raise NotImplementedError(
-            "CoTracker2 (cotracker.py:29-384) is outside the MI355X hot-path scope (SURVEY §8 a-9 / f-3); "
-            "use the CoTracker3 entry points.")
-    cls = CoTrackerThreeOffline if offline else CoTrackerThreeOnline
-    model = cls(stride=4, corr_radius=3, window_len=window_len)
+        model = CoTracker2(stride=4, window_len=window_len)
+    else:
+        cls = CoTrackerThreeOffline if offline else CoTrackerThreeOnline
+        model = cls(stride=4, corr_radius=3, window_len=window_len)
     if checkpoint is not None:
         with open(checkpoint, "rb") as f:
             state_dict = torch.load(f, map_location="cpu")

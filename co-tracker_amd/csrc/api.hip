@@ -86,8 +86,9 @@ UfWs carve_uf(int S, int N, void* base) {
 
 int attn(const float* q, long q_ld, long q_bs, long q_is, const float* k, const float* v, long kv_ld, long kv_bs,
          long kv_is, float* out, long o_bs, long o_is, int nbatch, int n1, int n2, int splits, float* partial,
-         hipStream_t s, bool o_split) {
+         hipStream_t s, bool o_split, const uint8_t* key_mask = nullptr, const uint8_t* query_mask = nullptr) {
   ctk_attn_args a;
+  a.key_mask = key_mask; a.query_mask = query_mask;
   a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.q_is = q_is;
   a.k = k; a.v = v; a.kv_ld = kv_ld; a.kv_bs = kv_bs; a.kv_is = kv_is;
   a.out = out; a.o_ld = o_split ? 2 * CTK_HID : CTK_HID; a.o_bs = o_bs; a.o_is = o_is; a.o_split = o_split;
@@ -116,10 +117,29 @@ int check_block(const ctk_block_weights& b, bool cross) {
   return CTK_OK;
 }
 
+// What run_transformer needs of a model: CoTracker3 (ctk_model_weights: 3 layers, no mask) and CoTracker2
+// (ctk_former_weights: 6 layers, per-point attention mask) share the block structure.
+struct FormerRef {
+  int depth;
+  const ctk_block_weights* time_blocks;
+  const ctk_block_weights* virtual2point;
+  const ctk_block_weights* virtual_self;
+  const ctk_block_weights* point2virtual;
+  const float* virtual_tokens;
+  const uint8_t* point_mask;  // CoTracker2 attention_mask per point (cotracker.py:343-345) or null
+  bool split;                 // xn / att / hid are SH-format (split-half back end)
+};
+
+FormerRef former_of(const ctk_model_weights* w) {
+  return FormerRef{CTK_DEPTH, w->time_blocks, w->virtual2point, w->virtual_self, w->point2virtual, w->virtual_tokens, nullptr,
+                   w->in_p != nullptr};
+}
+
 // EfficientUpdateFormer.forward (cotracker.py:483-531) on tokens already holding the input
 // projection in rows [0, N*S).
-int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hipStream_t s) {
-  const bool sp = split_mode(w);  // xn / att / hid are SH-format in split mode
+int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream_t s) {
+  const FormerRef* w = &fr;
+  const bool sp = fr.split;
   const long P = (long)N * S;             // point rows
   const long V = (long)CTK_VIRT * S;      // virtual rows
   const long R = P + V;
@@ -130,7 +150,7 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
   float* att = ws.att;
   CTK_TRY(ctk_launch_virtual_init(w->virtual_tokens, S, tok + P * CTK_HID, s));  // cotracker.py:487-488
 
-  for (int i = 0; i < CTK_DEPTH; ++i) {
+  for (int i = 0; i < fr.depth; ++i) {
     // ---- time attention over S for every track (incl. virtual)      cotracker.py:494-497
     {
       const ctk_block_weights& b = w->time_blocks[i];
@@ -150,7 +170,7 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
       CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       // batch = frame t; query i = virtual track (row P + i*S + t); key j = point (row j*S + t)
       CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S, CTK_VIRT, N,
-                   v2p_splits(N), ws.partial, s, sp));
+                   v2p_splits(N), ws.partial, s, sp, fr.point_mask, nullptr));  // mask over KEYS (cotracker.py:566-569)
       CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
                    tok + P * CTK_HID, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(mlp_block(ws, P, V, b, s, sp));
@@ -174,7 +194,8 @@ int run_transformer(int S, int N, const ctk_model_weights* w, const UfWs& ws, hi
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));           // norm_context(virtual)
       CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
-      CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s, sp));
+      CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s, sp,
+                   nullptr, fr.point_mask));  // mask over QUERIES (cotracker.py:561-564)
       CTK_TRY(gemm(att, CTK_HID, (int)P, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(mlp_block(ws, 0, P, b, s, sp));
     }
@@ -310,8 +331,40 @@ extern "C" int ctk_update_former(int32_t S, int32_t N, const float* x, const ctk
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   CTK_TRY(input_projection(S, N, x, false, w, ws, s));
-  CTK_TRY(run_transformer(S, N, w, ws, s));
+  CTK_TRY(run_transformer(S, N, former_of(w), ws, s));
   return ctk_launch_heads(ws.tokens, w->head_w, w->head_b, S, N, delta, nullptr, nullptr, nullptr, s);
+}
+
+// ---- general update former (CoTracker2: 6 + 6 layers, 456 -> 130, attention mask) ---------------------------
+extern "C" int ctk_update_former_ex(int32_t S, int32_t N, const void* x, int32_t x_split, const ctk_former_weights* w,
+                                    const uint8_t* point_mask, float* delta, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  if (!x || !delta || !workspace || !w) return CTK_E_NULL;
+  if (S <= 0 || N <= 0 || w->depth <= 0 || w->depth > 64) return CTK_E_SHAPE;
+  if (w->in_ld <= 0 || (w->in_ld % 32) || w->out_ld <= 0 || (w->out_ld % 64)) return CTK_E_SHAPE;
+  if ((!w->in_w && !w->in_p) || !w->virtual_tokens || (!w->head_w && !w->head_p) || !w->head_b) return CTK_E_NULL;
+  if (!w->time_blocks || !w->virtual2point || !w->virtual_self || !w->point2virtual) return CTK_E_NULL;
+  const bool sp = w->in_p != nullptr;
+  if (x_split && !sp) return CTK_E_SHAPE;
+  for (int i = 0; i < w->depth; ++i) {
+    CTK_TRY(check_block(w->time_blocks[i], false));
+    CTK_TRY(check_block(w->virtual2point[i], true));
+    CTK_TRY(check_block(w->virtual_self[i], false));
+    CTK_TRY(check_block(w->point2virtual[i], true));
+    if (sp != (w->time_blocks[i].wq_p != nullptr)) return CTK_E_NULL;
+  }
+  if (!ctk_aligned16(workspace)) return CTK_E_ALIGN;
+  const UfWs ws = carve_uf(S, N, workspace);
+  if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // tokens = input_transform(x) (+ per-frame bias rows = W e_t + b when in_bias_t is given, else + in_b)
+  CTK_TRY(gemm(static_cast<const float*>(x), w->in_ld, N * S, WRef{w->in_w, w->in_p}, w->in_ld, CTK_HID, w->in_ld, ws.tokens, CTK_HID,
+               w->in_bias_t ? nullptr : w->in_b, CTK_ACT_NONE, nullptr, 0, s, w->in_bias_t, S, 1, 0, 0, w->in_dim, x_split != 0, false));
+  const FormerRef fr{w->depth, w->time_blocks, w->virtual2point, w->virtual_self, w->point2virtual, w->virtual_tokens, point_mask, sp};
+  CTK_TRY(run_transformer(S, N, fr, ws, s));
+  // heads: delta[n*S+t][0..out_ld) = tokens @ head_w^T + head_b   (flow_head, cotracker.py:526)
+  return gemm(ws.tokens, CTK_HID, N * S, WRef{w->head_w, w->head_p}, CTK_HID, w->out_ld, CTK_HID, delta, w->out_ld, w->head_b, CTK_ACT_NONE,
+              nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, false, false);
 }
 
 extern "C" int ctk_corr_embed_workspace_bytes(const ctk_window_args* a, size_t* out_bytes) {
@@ -380,7 +433,7 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
     CTK_TRY(run_corr_embed(a, w, x, sp, cws, s));               // :190-210
     CTK_TRY(ctk_assemble_tokens(a, x, sp, s));                  // :212-245
     CTK_TRY(input_projection(a->S, a->N, x, sp, w, uws, s));    // :247 + cotracker.py:484
-    CTK_TRY(run_transformer(a->S, a->N, w, uws, s));            // :250
+    CTK_TRY(run_transformer(a->S, a->N, former_of(w), uws, s)); // :250
     CTK_TRY(ctk_launch_heads(uws.tokens, w->head_w, w->head_b, a->S, a->N, nullptr, a->coords, a->vis, a->conf, s));  // :252-259
   }
   return CTK_OK;

@@ -23,6 +23,7 @@ constexpr int HD = CTK_HEAD_DIM;  // 48
 constexpr int KC = 16;            // keys per LDS chunk
 constexpr int MAXB = 8;           // max batches packed into one wave (n1 >= 8)
 constexpr int BPAD = 4;           // floats between batches in LDS (bank spread)
+constexpr float NEG_MAX = -3.402823466e+38f;  // -torch.finfo(float32).max: the reference's mask bias (cotracker.py:571)
 
 struct AttnP {
   const float* q; long q_ld, q_bs, q_is;
@@ -37,6 +38,8 @@ struct AttnP {
   float scale;   // 48^-0.5
   float scale2;  // 48^-0.5 * log2(e): the MFMA kernels keep scores in the log2 domain (raw v_exp_f32, no multiply)
   int log2m;     // partial maxima are in the log2 domain (attention_q64_kernel) -> the merge uses exp2
+  const uint8_t* kmask;  // [n2] or null: masked keys get logit -FLT_MAX (CoTracker2)
+  const uint8_t* qmask;  // [n1] or null: a masked query attends uniformly
 };
 
 __global__ __launch_bounds__(64) void attention_kernel(AttnP p) {
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnP p) {
 #pragma unroll
   for (int d = 0; d < HD; ++d) acc[d] = 0.0f;
   float m = -INFINITY, l = 0.0f;
+  const bool qmasked = p.qmask && !p.qmask[myq];
 
   const int kbeg = split * p.keys_per_split;
   const int kend = min(p.n2, kbeg + p.keys_per_split);
@@ -109,6 +113,8 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnP p) {
           const f32x4 t = *reinterpret_cast<const f32x4*>(myk + kk * HD + d);
           dot += qr[d] * t[0] + qr[d + 1] * t[1] + qr[d + 2] * t[2] + qr[d + 3] * t[3];
         }
+        if (p.kmask && !p.kmask[k0 + kk]) dot = NEG_MAX;
+        if (qmasked) dot = NEG_MAX;
         cmax = fmaxf(cmax, dot);
       } else {
         dot = -INFINITY;
@@ -248,6 +254,16 @@ __global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
         const f16x8 kl = *reinterpret_cast<const f16x8*>(ka + 64 * KP);
         sacc[kt] = ctk_mma3(kh, kl, qh[j], ql[j], sacc[kt]);
       }
+    }
+    if (p.kmask || p.qmask) {  // CoTracker2 masks: masked keys / every key of a masked query -> the same huge negative logit
+      const bool qm = p.qmask && !p.qmask[qi];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = 32 * kt + 8 * (e >> 2) + 4 * half + (e & 3);
+          if (qm || (p.kmask && !p.kmask[key])) sacc[kt][e] = NEG_MAX;
+        }
     }
     // softmax over the 64 keys of my query: 32 values here, 32 in lane ^ 32
     float mx = -INFINITY;
@@ -395,6 +411,16 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
       for (int e = 0; e < 16; ++e) sacc[qt][e] = 0.0f;
 #pragma unroll
       for (int j = 0; j < 3; ++j) sacc[qt] = ctk_mma3(kh[j], kl[j], qh[qt][j], ql[qt][j], sacc[qt]);
+    }
+    if (p.kmask || p.qmask) {  // CoTracker2 masks (finite bias: a fully masked row stays a uniform softmax)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = min(k0 + 8 * (e >> 2) + 4 * half + (e & 3), kend - 1);
+        const bool km = p.kmask && !p.kmask[key];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          if (km || (p.qmask && !p.qmask[qt * 32 + r32])) sacc[qt][e] = NEG_MAX;
+      }
     }
     if (k0 + 32 > kend) {  // ragged last tile: keys past the split's range get probability 0
 #pragma unroll
@@ -582,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
     for (int e = 0; e < 16; ++e) {
       const int slot = 8 * (e >> 2) + 4 * half + (e & 3);
       const bool ok = (slot / spb == qb) && (b0 + slot / spb < p.nbatch) && (kt * spb + slot % spb < p.n2);
+      if (ok && ((p.kmask && !p.kmask[min(kt * spb + slot % spb, p.n2 - 1)]) || (p.qmask && !p.qmask[qic]))) sacc[e] = NEG_MAX;
       sacc[e] = ok ? sacc[e] : -INFINITY;
       tmax = fmaxf(tmax, sacc[e]);
     }
@@ -692,6 +719,8 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
   p.splits = a->splits > 1 ? a->splits : 1;
   if (p.splits > 1 && !a->partial) return CTK_E_NULL;
   p.partial = a->partial;
+  p.kmask = a->key_mask;
+  p.qmask = a->query_mask;
   p.scale = 0.14433756729740643f;  // 48 ** -0.5 (blocks.py:372)
   p.scale2 = 0.14433756729740643f * 1.4426950408889634f;
   p.log2m = 0;

@@ -56,3 +56,221 @@ class CoTracker2(nn.Module):
         self.norm = _Affine128(self.latent_dim)
         self.track_feat_updater = nn.Sequential(_Lin(self.latent_dim, self.latent_dim))  # + nn.GELU() (no parameters)
         self.vis_predictor = nn.Sequential(_Lin(self.latent_dim, 1))
+        self._packed = None
+        from . import model as _m
+        self.precision = _m.DEFAULT_PRECISION  # Linear back end: "f16x3" (split-half MFMA) | "f32"; not a reference kwarg
+
+
+# ------------------------------------------------------------------------------------------
+# device-side packed weights (ctk_former_weights of include/ctk.h)
+# ------------------------------------------------------------------------------------------
+import torch.nn.functional as F  # noqa: E402
+
+from . import _lib as L  # noqa: E402
+from . import ops  # noqa: E402
+
+IN_LD, OUT_LD, DEPTH_V2 = 480, 192, 6  # input_dim 456 / output_dim 130 padded for the GEMM tiles
+
+
+class PackedWeightsV2:
+    def __init__(self, model: "CoTracker2", device, precision: str = "f16x3"):
+        if precision not in ("f16x3", "f32"):
+            raise ValueError("precision must be 'f16x3' (split-half MFMA, default) or 'f32' (exact-f32 MFMA)")
+        self.precision, self.device = precision, device
+        split = precision == "f16x3"
+        sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in model.state_dict().items()}
+        self.keep = []
+
+        def hold(t):
+            t = t.contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def pack(t):
+            if not split:
+                return None
+            blob = ops.pack_weight(t.contiguous())
+            self.keep.append(blob)
+            return blob.data_ptr()
+
+        u = "updateformer."
+        fw = L.FormerWeights()
+        fw.depth, fw.in_dim, fw.in_ld, fw.out_dim, fw.out_ld = DEPTH_V2, model.input_dim, IN_LD, model.latent_dim + 2, OUT_LD
+        in_w = torch.zeros(384, IN_LD, device=device)
+        in_w[:, : model.input_dim] = sd[u + "input_transform.weight"]
+        fw.in_w, fw.in_p = hold(in_w), pack(in_w)
+        fw.in_b = hold(sd[u + "input_transform.bias"])
+        # time embedding folded into per-frame bias rows: W (x + e_t) + b = W x + (W e_t + b)   (cotracker.py:150,484)
+        te = sd["time_emb"][0].double()
+        bias_t = (te @ sd[u + "input_transform.weight"].double().t() + sd[u + "input_transform.bias"].double()).float()
+        fw.in_bias_t = hold(bias_t)
+        fw.virtual_tokens = hold(sd[u + "virual_tracks"].reshape(64, 384))
+        head_w = torch.zeros(OUT_LD, 384, device=device)
+        head_w[: model.latent_dim + 2] = sd[u + "flow_head.weight"]
+        head_b = torch.zeros(OUT_LD, device=device)
+        head_b[: model.latent_dim + 2] = sd[u + "flow_head.bias"]
+        fw.head_w, fw.head_p, fw.head_b = hold(head_w), pack(head_w), hold(head_b)
+
+        def block(prefix, attn_name, cross):
+            b = L.BlockWeights()
+            a = f"{prefix}{attn_name}."
+            b.wq, b.bq = hold(sd[a + "to_q.weight"]), hold(sd[a + "to_q.bias"])
+            b.wkv, b.bkv = hold(sd[a + "to_kv.weight"]), hold(sd[a + "to_kv.bias"])
+            b.wo, b.bo = hold(sd[a + "to_out.weight"]), hold(sd[a + "to_out.bias"])
+            b.w1, b.b1 = hold(sd[prefix + "mlp.fc1.weight"]), hold(sd[prefix + "mlp.fc1.bias"])
+            b.w2, b.b2 = hold(sd[prefix + "mlp.fc2.weight"]), hold(sd[prefix + "mlp.fc2.bias"])
+            b.wq_p, b.wkv_p, b.wo_p = pack(sd[a + "to_q.weight"]), pack(sd[a + "to_kv.weight"]), pack(sd[a + "to_out.weight"])
+            b.w1_p, b.w2_p = pack(sd[prefix + "mlp.fc1.weight"]), pack(sd[prefix + "mlp.fc2.weight"])
+            if cross:
+                b.ctx_gamma, b.ctx_beta = hold(sd[prefix + "norm_context.weight"]), hold(sd[prefix + "norm_context.bias"])
+            return b
+
+        Arr = L.BlockWeights * DEPTH_V2
+        self.arrays = [Arr(*[block(f"{u}{name}.{i}.", attn, cross) for i in range(DEPTH_V2)])
+                       for name, attn, cross in (("time_blocks", "attn", False), ("space_virtual2point_blocks", "cross_attn", True),
+                                                 ("space_virtual_blocks", "attn", False), ("space_point2virtual_blocks", "cross_attn", True))]
+        fw.time_blocks, fw.virtual2point, fw.virtual_self, fw.point2virtual = self.arrays
+        self.former = fw
+        self.split = split
+        self.pos_hwc = sd["pos_emb"][0].permute(1, 2, 0).contiguous()  # [H/4, W/4, 456]
+        self.norm_w, self.norm_b = sd["norm.weight"].contiguous(), sd["norm.bias"].contiguous()
+        self.upd_w, self.upd_b = sd["track_feat_updater.0.weight"].contiguous(), sd["track_feat_updater.0.bias"].contiguous()
+        self.upd_p = ops.pack_weight(self.upd_w) if split else None
+        self.vis_w, self.vis_b = sd["vis_predictor.0.weight"].reshape(128).contiguous(), sd["vis_predictor.0.bias"].contiguous()
+
+
+def _v2_forward_window(self, pyr, coords, track_feat, vis, track_mask, point_mask, iters, pw):
+    """CoTracker2.forward_window (cotracker.py:86-173) for one batch element.  pyr: 4 x [S,H_l,W_l,128] (NOT normalised),
+    coords [S,N,2] feature units, track_feat [S,N,128] (already masked), vis [S,N], track_mask [S,N] float 0/1,
+    point_mask [N] uint8.  Returns (coords [S,N,2] feature units, vis logits [S,N])."""
+    S, N = coords.shape[0], coords.shape[1]
+    coords = coords.clone()
+    track_feat = track_feat.clone()
+    pos = ops.sample_features4d(pw.pos_hwc, coords[0].contiguous())  # sampled_pos_emb, :126-130
+    for _ in range(iters):
+        fcorrs = ops.corrblock_sample(pyr, track_feat, coords)                          # :134-137
+        x = ops.v2_assemble(coords, fcorrs, track_feat, track_mask, vis, pos, IN_LD, pw.split)   # :139-150
+        delta = ops.update_former_ex(x, pw.split, S, N, pw.former, point_mask)         # :152-155
+        normed = ops.v2_apply_delta(delta, coords, pw.norm_w, pw.norm_b, 1e-5)         # :157-159 + GroupNorm of :167
+        tf2 = track_feat.view(S * N, 128)
+        ops.gemm(normed, pw.upd_w, bias=pw.upd_b, act=L.ACT_GELU_ERF, resid=tf2, out=tf2, packed=pw.upd_p)  # :162-170
+    return coords, ops.v2_vis_head(track_feat, pw.vis_w, pw.vis_b)                      # :172
+
+
+def _v2_init_online(self):  # cotracker.py:187-191
+    self.online_ind = 0
+    self.online_track_feat = None
+    self.online_coords_predicted = None
+    self.online_vis_predicted = None
+
+
+@torch.no_grad()
+def _v2_forward(self, video, queries, iters=4, is_train=False, is_online=False):
+    """CoTracker2.forward (cotracker.py:193-384): returns (coords [B,T,N,2] px, vis [B,T,N] post-sigmoid, None)."""
+    if is_train:
+        raise NotImplementedError("inference-only implementation (training is out of scope)")
+    if not video.is_cuda:
+        raise RuntimeError("cotracker_amd runs on an MI355X GPU only: move the model and inputs to 'cuda'. There is no CPU path.")
+    B, T, C_, H, W = video.shape
+    S = self.window_len
+    assert S >= 2
+    if is_online:
+        assert T <= S, "Online mode: video chunk must be <= window size."
+        assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
+        if B != 1:
+            raise NotImplementedError("online mode supports B=1")
+    outs = [self._forward_one(video[b], queries[b], iters, is_online) for b in range(B)]
+    return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), None
+
+
+def _v2_forward_one(self, video, queries, iters, is_online):
+    T, N = video.shape[0], queries.shape[0]
+    S, step, dev = self.window_len, self.window_len // 2, video.device
+    pw = self.packed(dev)
+    queries = queries.float()
+    qframes = queries[:, 0].long()
+    qcoords = (queries[:, 1:3] / self.stride).contiguous()
+    coords_pred = torch.zeros(T, N, 2, device=dev)
+    vis_pred = torch.zeros(T, N, device=dev)
+    if is_online and self.online_coords_predicted is not None:  # :247-259
+        p = min(step, T - step)
+        coords_pred = F.pad(self.online_coords_predicted, (0, 0, 0, 0, 0, p))
+        vis_pred = F.pad(self.online_vis_predicted, (0, 0, 0, p))
+    # encoder; padding the video with its last frame (:264-270) == repeating the last feature map (fnet is per-frame)
+    pad = (S - T) if is_online else (S - T % S) % S
+    f0 = self.fnet(2 * (video.float() / 255.0) - 1.0).float().permute(0, 2, 3, 1).contiguous()  # NHWC, not normalised
+    if pad > 0:
+        f0 = torch.cat([f0, f0[-1:].expand(pad, -1, -1, -1)], dim=0).contiguous()
+    pyr = ops.build_pyramid(f0, 4)  # CorrBlock pyramid (blocks.py:300-307) for every frame at once
+    # get_track_feat (:175-185): trilinear sample at (t, x, y) = the centre tap of the support sampler
+    frames_rel = (qframes - self.online_ind if is_online else qframes).float().contiguous()
+    tf0 = ops.sample_support(f0, frames_rel, qcoords)[:, 24].contiguous()  # [N,128]
+    track_feat = tf0[None].expand(S, N, 128)
+    if is_online:  # :286-295
+        left = 0 if self.online_ind == 0 else self.online_ind + step
+        right = self.online_ind + S
+        smask = ((qframes >= left) & (qframes < right)).float()[None, :, None]
+        if self.online_track_feat is None:
+            self.online_track_feat = torch.zeros(S, N, 128, device=dev)
+        self.online_track_feat = self.online_track_feat + track_feat * smask
+        track_feat = self.online_track_feat
+    num_windows = (T - S + step - 1) // step + 1
+    indices = [self.online_ind] if is_online else range(0, step * num_windows, step)
+    coords_init = qcoords[None].expand(S, N, 2).contiguous()
+    vis_init = torch.full((S, N), 10.0, device=dev)
+    for ind in indices:
+        overlap = S - step
+        if ind > 0:  # :306-327
+            copy_over = (qframes < ind + overlap)[None, :]
+            cprev = coords_pred[ind:ind + overlap] / self.stride
+            cprev = torch.cat([cprev, cprev[-1:].expand(step, -1, -1)], dim=0)
+            vprev = vis_pred[ind:ind + overlap]
+            vprev = torch.cat([vprev, vprev[-1:].expand(step, -1)], dim=0)
+            coords_init = torch.where(copy_over[..., None], cprev, coords_init).contiguous()
+            vis_init = torch.where(copy_over, vprev, vis_init).contiguous()
+        amask = qframes < ind + S                                                        # attention_mask, :331-333
+        tmask = qframes[None, :] <= torch.arange(ind, ind + S, device=dev)[:, None]      # track_mask, :338-344
+        if ind > 0:
+            tmask = tmask.clone()
+            tmask[:overlap] = False
+        win_pyr = pyr if is_online else [p_[ind:ind + S] for p_ in pyr]
+        coords, vis = self.forward_window(win_pyr, coords_init, (track_feat * amask.float()[None, :, None]).contiguous(), vis_init,
+                                          tmask.float().contiguous(), amask.to(torch.uint8).contiguous(), iters, pw)
+        S_trim = T if is_online else min(T - ind, S)
+        coords_pred[ind:ind + S] = (coords * float(self.stride))[:S_trim]
+        vis_pred[ind:ind + S] = vis[:S_trim]
+    if is_online:
+        self.online_ind += step
+        self.online_coords_predicted = coords_pred
+        self.online_vis_predicted = vis_pred
+    return coords_pred, torch.sigmoid(vis_pred)
+
+
+def _v2_packed(self, device):
+    if self._packed is None or self._packed.device != device or self._packed.precision != self.precision:
+        self._packed = PackedWeightsV2(self, device, self.precision)
+    return self._packed
+
+
+def _v2_invalidate(self):
+    self._packed = None
+
+
+def _v2_load_state_dict(self, *args, **kwargs):
+    self._packed = None
+    return nn.Module.load_state_dict(self, *args, **kwargs)
+
+
+def _v2_apply(self, fn, *args, **kwargs):
+    self._packed = None
+    return nn.Module._apply(self, fn, *args, **kwargs)
+
+
+CoTracker2.forward_window = _v2_forward_window
+CoTracker2.init_video_online_processing = _v2_init_online
+CoTracker2.forward = _v2_forward
+CoTracker2._forward_one = _v2_forward_one
+CoTracker2.packed = _v2_packed
+CoTracker2.invalidate_packed_weights = _v2_invalidate
+CoTracker2.load_state_dict = _v2_load_state_dict
+CoTracker2._apply = _v2_apply

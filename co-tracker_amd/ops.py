@@ -108,7 +108,8 @@ def layernorm(x: torch.Tensor, gamma=None, beta=None, eps: float = 1e-6, out_spl
     return y
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, splits: int = 1, out_split: bool = False) -> torch.Tensor:
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, splits: int = 1, out_split: bool = False,
+              key_mask: Optional[torch.Tensor] = None, query_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [B,N1,384], k/v [B,N2,384] (8 heads x 48, heads contiguous in the last dim) -> [B,N1,384]
     (or its SH form [B*N1, 12, 2, 32] float16 when out_split)."""
     _chk_f32(q, k, v)
@@ -126,6 +127,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, splits: int = 1
     if splits > 1:
         part = torch.empty(splits * B * 8 * N1 * 50, device=q.device, dtype=torch.float32)
     a.partial = _ptr(part)
+    a.key_mask, a.query_mask = _ptr(key_mask), _ptr(query_mask)  # uint8 [N2] / [N1] (CoTracker2 attention mask)
     L.check(L.load().ctk_attention(C.byref(a), _stream()), "ctk_attention")
     return out
 
@@ -197,6 +199,67 @@ def corrblock_sample(pyr_nhwc: Sequence[torch.Tensor], targets: torch.Tensor, co
             "ctk_corrblock_sample")
     return out
 
+
+
+# ------------------------------------------------------------------------------------------
+# CoTracker2 iteration (cotracker.py:86-173): row kernels + the general update former
+# ------------------------------------------------------------------------------------------
+def sample_features4d(map_hwc: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """sample_features4d (model_utils.py:258-290): channels-last map [H,W,C] sampled at coords [N,2]=(x,y) -> [N,C]."""
+    _chk_f32(map_hwc, coords)
+    H, W, Cc = map_hwc.shape
+    N = coords.shape[0]
+    out = torch.empty(N, Cc, device=coords.device, dtype=torch.float32)
+    L.check(L.load().ctk_sample_features4d(_ptr(map_hwc), H, W, Cc, _ptr(coords), N, _ptr(out), _stream()), "ctk_sample_features4d")
+    return out
+
+
+def v2_assemble(coords, fcorrs, track_feat, track_mask, vis, pos, in_ld: int, out_split: bool) -> torch.Tensor:
+    """Transformer input of CoTracker2 (cotracker.py:135-150 without the time embedding): [N*S, in_ld] f32 or SH."""
+    _chk_f32(coords, fcorrs, track_feat, track_mask, vis, pos)
+    S, N = coords.shape[0], coords.shape[1]
+    assert fcorrs.shape == (N, S, 196) and track_feat.shape == (S, N, 128) and pos.shape == (N, 456)
+    assert track_mask.shape == (S, N) and vis.shape == (S, N)
+    x = (torch.empty(N * S, in_ld // 32, 2, 32, device=coords.device, dtype=torch.float16) if out_split
+         else torch.empty(N * S, in_ld, device=coords.device, dtype=torch.float32))
+    L.check(L.load().ctk_v2_assemble(S, N, _ptr(coords), _ptr(fcorrs), _ptr(track_feat), _ptr(track_mask), _ptr(vis), _ptr(pos),
+                                     in_ld, _ptr(x), int(out_split), _stream()), "ctk_v2_assemble")
+    return x
+
+
+def v2_apply_delta(delta: torch.Tensor, coords: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """coords [S,N,2] += delta[:, :2] in place; returns GroupNorm(1,128)(delta[:, 2:130]) as [S*N,128] (row t*N+n)."""
+    _chk_f32(delta, coords, gamma, beta)
+    S, N = coords.shape[0], coords.shape[1]
+    assert delta.shape[0] == N * S
+    normed = torch.empty(S * N, 128, device=coords.device, dtype=torch.float32)
+    L.check(L.load().ctk_v2_apply_delta(S, N, _ptr(delta), delta.shape[1], _ptr(coords), _ptr(gamma), _ptr(beta), float(eps),
+                                        _ptr(normed), _stream()), "ctk_v2_apply_delta")
+    return normed
+
+
+def v2_vis_head(track_feat: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """vis_predictor (cotracker.py:172): track_feat [S,N,128] -> logits [S,N]."""
+    _chk_f32(track_feat, w, b)
+    S, N, _ = track_feat.shape
+    out = torch.empty(S, N, device=track_feat.device, dtype=torch.float32)
+    L.check(L.load().ctk_v2_vis_head(_ptr(track_feat), S * N, _ptr(w), _ptr(b), _ptr(out), _stream()), "ctk_v2_vis_head")
+    return out
+
+
+def update_former_ex(x: torch.Tensor, x_split: bool, S: int, N: int, fw: "L.FormerWeights", point_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """General EfficientUpdateFormer.forward (cotracker.py:483-531) with the CoTracker2 attention mask:
+    x [N*S, in_ld] (f32 or SH) -> delta [N*S, out_ld] f32."""
+    lib = L.load()
+    nbytes = C.c_size_t(0)
+    L.check(lib.ctk_update_former_workspace_bytes(S, N, C.byref(nbytes)), "ctk_update_former_workspace_bytes")
+    ws = _workspace(nbytes.value, x.device)
+    delta = torch.empty(N * S, fw.out_ld, device=x.device, dtype=torch.float32)
+    if point_mask is not None:
+        assert point_mask.dtype == torch.uint8 and point_mask.shape == (N,) and point_mask.is_cuda
+    L.check(lib.ctk_update_former_ex(S, N, _ptr(x), int(x_split), C.byref(fw), _ptr(point_mask), _ptr(delta), _ptr(ws), ws.numel(),
+                                     _stream()), "ctk_update_former_ex")
+    return delta
 
 # ------------------------------------------------------------------------------------------
 # window-level ops

@@ -143,7 +143,8 @@ class CoTrackerOnlinePredictor(torch.nn.Module):
         self.step = model.window_len // 2
         self.model = model
         self.model.eval()
-        self.model.hip_graph = True  # streaming: replay the captured window graph per chunk (configs[3])
+        if not v2:
+            self.model.hip_graph = True  # streaming: replay the captured window graph per chunk (configs[3])
 
     @torch.no_grad()
     def forward(self, video_chunk, is_first_step: bool = False, queries: torch.Tensor = None, grid_size: int = 5,
@@ -169,8 +170,14 @@ class CoTrackerOnlinePredictor(torch.nn.Module):
 
         v = F.interpolate(video_chunk.reshape(B * T, C, H, W).float(), tuple(self.interp_shape), mode="bilinear",
                           align_corners=True).reshape(B, T, 3, ih, iw)
-        tracks, vis, conf, _ = self.model(video=v, queries=self.queries, iters=6, is_online=True)
+        if self.v2:  # CoTracker2 returns (tracks, visibility, train_data): no confidence (predictor.py:283-286)
+            tracks, vis, _ = self.model(video=v, queries=self.queries, iters=6, is_online=True)
+            conf = None
+        else:
+            tracks, vis, conf, _ = self.model(video=v, queries=self.queries, iters=6, is_online=True)
         if add_support_grid:
-            tracks, vis, conf = tracks[:, :, :self.N], vis[:, :, :self.N], conf[:, :, :self.N]
-        vis = vis * conf  # predictor.py:297-298
+            tracks, vis = tracks[:, :, :self.N], vis[:, :, :self.N]
+            conf = conf[:, :, :self.N] if conf is not None else None
+        if conf is not None:
+            vis = vis * conf  # predictor.py:297-298
         return tracks * tracks.new_tensor([(W - 1) / (iw - 1), (H - 1) / (ih - 1)]), vis > 0.6

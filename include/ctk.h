@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 3
+#define CTK_ABI_VERSION 4
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -170,6 +170,48 @@ int ctk_update_former_workspace_bytes(int32_t S, int32_t N, size_t* out_bytes);
 int ctk_update_former(int32_t S, int32_t N, const float* x, const ctk_model_weights* w,
                       float* delta /*[N*S,4] row=n*S+t*/, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- general update former: CoTracker2 (cotracker.py:46-56: time_depth = space_depth = 6, input_dim 456,
+ * output_dim 130, attention mask) on the same block kernels.  x [N*S, in_ld] (f32, or SH when x_split), row = n*S+t,
+ * columns >= in_dim zero; delta [N*S, out_ld] f32 (columns >= out_dim are the zero-padded head rows).  point_mask [N]
+ * (1 = track already queried) masks the point KEYS of virtual<-points and the point QUERIES of points<-virtual exactly
+ * as CrossAttnBlock.forward does (cotracker.py:560-572); NULL = no mask.  Workspace: ctk_update_former_workspace_bytes. */
+typedef struct ctk_former_weights {
+  int32_t depth;               /* layers (6)                                                     */
+  int32_t in_dim, in_ld;       /* 456, padded to a multiple of 32 (480)                          */
+  int32_t out_dim, out_ld;     /* 130, padded to a multiple of 64 (192)                          */
+  const float* in_w;           /* input_transform.weight [384, in_ld] (zero padded) or NULL when in_p */
+  const void* in_p;            /* ctk_pack_weight blob: selects the split-half back end for EVERY Linear */
+  const float* in_b;           /* input_transform.bias [384] (used when in_bias_t == NULL)       */
+  const float* in_bias_t;      /* optional [S,384] = bias + W @ time_emb[t] (time embedding folded in) */
+  const float* virtual_tokens; /* virual_tracks [64,384]                                         */
+  const float* head_w;         /* flow_head.weight [out_ld,384] zero padded rows, or NULL when head_p */
+  const void* head_p;
+  const float* head_b;         /* [out_ld]                                                       */
+  const ctk_block_weights* time_blocks;    /* [depth] */
+  const ctk_block_weights* virtual2point;  /* [depth] */
+  const ctk_block_weights* virtual_self;   /* [depth] */
+  const ctk_block_weights* point2virtual;  /* [depth] */
+} ctk_former_weights;
+int ctk_update_former_ex(int32_t S, int32_t N, const void* x, int32_t x_split, const ctk_former_weights* w,
+                         const uint8_t* point_mask, float* delta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* CoTracker2 iteration around CorrBlock and the former (cotracker.py:128-172).  Layouts: coords / track_mask / vis
+ * [S,N,*], track_feat [S,N,128] (= CorrBlock targets), fcorrs [N,S,196] (ctk_corrblock_sample), pos [N,456].
+ * ctk_v2_assemble: x[n*S+t][0..in_ld) = cat(get_2d_embedding(coords - coords[0]) (130), fcorrs (196), track_feat (128),
+ *   track_mask, vis) + pos[n], zero padded to in_ld; the time embedding (:150) is folded into in_bias_t.
+ * ctk_v2_apply_delta: coords[t,n] += delta[n*S+t][0:2]; normed[t*N+n][0:128] = GroupNorm(1,128)(delta[n*S+t][2:130])
+ *   (:157-167; the Linear + GELU + residual of track_feat_updater is then one ctk_gemm with resid = C = track_feat).
+ * ctk_v2_vis_head: vis_predictor (:172).  ctk_sample_features4d: sample_features4d (model_utils.py:258-290) of a
+ *   channels-last map [H,W,C] at (x, y) -> [N,C] (4-D grid_sample semantics; used for pos_emb, :126-130).          */
+int ctk_v2_assemble(int32_t S, int32_t N, const float* coords, const float* fcorrs, const float* track_feat,
+                    const float* track_mask, const float* vis, const float* pos, int32_t in_ld, void* x, int32_t x_split,
+                    void* stream);
+int ctk_v2_apply_delta(int32_t S, int32_t N, const float* delta, int32_t out_ld, float* coords, const float* gamma,
+                       const float* beta, float eps, float* normed, void* stream);
+int ctk_v2_vis_head(const float* track_feat, int64_t R, const float* w, const float* b, float* out, void* stream);
+int ctk_sample_features4d(const float* map, int32_t H, int32_t W, int32_t C, const float* coords, int32_t N, float* out,
+                          void* stream);
+
 /* ---- Op D: standalone samplers --------------------------------------------------- */
 /* Integer floor indices (x0,y0) of the 7 x-taps and 7 y-taps of every (t,n,level), exactly as
  * bilinear_sampler + ATen grid_sampler_3d compute them (model_utils.py:238-255).
@@ -247,6 +289,12 @@ typedef struct ctk_attn_args {
   int32_t splits;          /* key-range splits (>1 needs workspace) */
   float* partial;          /* [splits, nbatch, 8, n1, 50] or NULL    */
   int32_t o_split;         /* write out in SH format                 */
+  /* CoTracker2's attention_mask (CrossAttnBlock.forward, cotracker.py:560-572), one flag per point, shared by all
+   * batches (frames) and heads; NULL = no mask.  key_mask[j] == 0: key j gets logit -FLT_MAX (probability 0 unless
+   * every key is masked, then uniform -- exactly the reference's additive bias).  query_mask[i] == 0: every logit of
+   * query i is -FLT_MAX, i.e. that query attends uniformly (the reference's quirk for not-yet-queried tracks).   */
+  const uint8_t* key_mask;   /* [n2] */
+  const uint8_t* query_mask; /* [n1] */
 } ctk_attn_args;
 int ctk_attention(const ctk_attn_args* a, void* stream);
 

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SYMBOLS), f"binding/header mismatch: {declared ^ set(_lib.SYMBOLS)}"
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_argument_validation_without_gpu(lib):
@@ -79,8 +79,10 @@ def test_model_fails_loudly_on_cpu_tensors():
     m = build_cotracker(None, offline=False, window_len=8).eval()
     with pytest.raises(RuntimeError, match="GPU only"):
         m(torch.zeros(1, 8, 3, 64, 64), torch.zeros(1, 2, 3))
-    with pytest.raises(NotImplementedError):
-        build_cotracker(None, v2=True)
+    v2 = build_cotracker(None, v2=True, window_len=8).eval()  # CoTracker2: same contract
+    assert len(v2.state_dict()) == 321 and v2.window_len == 8 and v2.model_resolution == (384, 512)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        v2(torch.zeros(1, 8, 3, 64, 64), torch.zeros(1, 2, 3))
 
 
 def test_time_embedding_fold_matches_reference_order():

@@ -649,3 +649,130 @@ def test_full_size_properties():
     for x, y in zip(a, c):
         assert maxdiff(x, y) == 0.0          # chunking of the correlation stage does not change results
     assert torch.isfinite(a[0]).all() and float((a[0] - qc[None]).abs().max()) > 1e-3
+
+
+# ------------------------------------------------------------------------------------------
+# CoTracker2: masked attention, the general update former, forward_window, full model
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("backend", ["mfma", "valu"])
+@pytest.mark.parametrize("B,N1,N2,splits,which", [(8, 64, 700, 3, "key"), (8, 300, 64, 1, "query"), (3, 64, 64, 1, "key"),
+                                                   (5, 16, 16, 1, "key"), (2, 64, 256, 1, "all_keys_masked")])
+def test_attention_masks(B, N1, N2, splits, which, backend, monkeypatch):
+    """CrossAttnBlock's additive -FLT_MAX bias (cotracker.py:560-572): masked keys drop out, a masked query (or a
+    row whose keys are all masked) attends uniformly."""
+    from cotracker_amd import ops
+    monkeypatch.setenv("CTK_ATTN", "1" if backend == "valu" else "0")
+    g = torch.Generator().manual_seed(B * 100 + N1 + N2)
+    q = torch.randn(B, N1, 384, generator=g).to(dev())
+    k = torch.randn(B, N2, 384, generator=g).to(dev())
+    v = torch.randn(B, N2, 384, generator=g).to(dev())
+    km = qm = None
+    if which == "key":
+        km = (torch.rand(N2, generator=g) > 0.3).to(torch.uint8)
+        km[0] = 1
+    elif which == "all_keys_masked":
+        km = torch.zeros(N2, dtype=torch.uint8)
+    else:
+        qm = (torch.rand(N1, generator=g) > 0.3).to(torch.uint8)
+    out = ops.attention(q, k, v, splits=splits, key_mask=None if km is None else km.to(dev()),
+                        query_mask=None if qm is None else qm.to(dev()))
+    qh = q.double().reshape(B, N1, 8, 48).transpose(1, 2)
+    kh = k.double().reshape(B, N2, 8, 48).transpose(1, 2)
+    vh = v.double().reshape(B, N2, 8, 48).transpose(1, 2)
+    sim = qh @ kh.transpose(-1, -2) * 48 ** -0.5
+    neg = -torch.finfo(torch.float32).max
+    if km is not None:
+        sim = torch.where(km.bool().to(dev())[None, None, None, :], sim, torch.full_like(sim, neg))
+    if qm is not None:
+        sim = torch.where(qm.bool().to(dev())[None, None, :, None], sim, torch.full_like(sim, neg))
+    ref = (torch.softmax(sim, -1) @ vh).transpose(1, 2).reshape(B, N1, 384)
+    assert maxdiff(out, ref) < 5e-6
+
+
+def _v2_model(precision):
+    from cotracker_amd.model_v2 import CoTracker2
+    from cotracker_amd.weights import fill_synthetic_
+    m = CoTracker2(window_len=8, stride=4, model_resolution=(64, 96)).eval()
+    m.precision = precision
+    fill_synthetic_(m, seed=6, head_scale=1.0)
+    return m.to(dev())
+
+
+def test_cotracker2_update_former(golden, precision):
+    """ctk_update_former_ex (6+6 layers, 456 -> 130, per-point attention mask) vs the reference's EfficientUpdateFormer."""
+    from cotracker_amd import ops
+    g = golden("cotracker2")
+    m = _v2_model(precision)
+    pw = m.packed(dev())
+    x = g["uf_x"][0]                      # [N,S,456]
+    N, S = x.shape[:2]
+    xp = np.zeros((N * S, 480), np.float32)
+    xp[:, :456] = x.reshape(N * S, 456)
+    mask = torch.from_numpy(g["uf_mask"][0].astype(np.uint8)).to(dev())  # the reference's [B*S,N] mask is per point
+    assert (g["uf_mask"] == g["uf_mask"][0:1]).all()
+    saved = pw.former.in_bias_t
+    pw.former.in_bias_t = None            # the golden feeds the former directly: plain bias, no time embedding
+    try:
+        xin = t(xp)
+        if pw.split:
+            xin = ops.split_rows(xin)
+        delta = ops.update_former_ex(xin, pw.split, S, N, pw.former, mask)
+    finally:
+        pw.former.in_bias_t = saved
+    ours = delta[:, :130].reshape(N, S, 130)
+    assert float(delta[:, 130:].abs().max()) == 0.0
+    assert maxdiff(ours, g["uf_delta"][0]) < 1e-4
+
+
+def test_cotracker2_forward_window(golden, precision):
+    g = golden("cotracker2")
+    m = _v2_model(precision)
+    pw = m.packed(dev())
+    from cotracker_amd import ops
+    f0 = t(np.ascontiguousarray(g["fw_fmaps"][0].transpose(0, 2, 3, 1)))   # NHWC
+    pyr = ops.build_pyramid(f0, 4)
+    amask = g["fw_attention_mask"][0]                                       # [S,N], identical rows
+    tf = t((amask[..., None] * g["fw_track_feat"][0]).astype(np.float32))
+    coords, vis = m.forward_window(pyr, t(g["fw_coords"][0]), tf, t(g["fw_vis"][0, ..., 0]),
+                                   t(g["fw_track_mask"][0, ..., 0].astype(np.float32)),
+                                   torch.from_numpy(amask[0].astype(np.uint8)).to(dev()), 3, pw)
+    assert maxdiff(coords * 4.0, g["fw_out_coords"][0]) < 1e-3
+    # visibility logits (|v| ~ 4) are read off track features that went through 3 chaotic updates: 1e-4 relative
+    assert maxdiff(vis, g["fw_out_vis"][0]) < 2e-3
+
+
+def test_cotracker2_model_sliding_and_streaming(golden, precision):
+    """Full CoTracker2 forwards incl. encoder vs the reference (1 iteration per window: with random weights the
+    CoTracker2 iteration is chaotic, see tests/golden/make_golden.py)."""
+    g = golden("cotracker2")
+    m = _v2_model(precision)
+    video, q = t(g["video"]), t(g["queries"])
+    c, v, extra = m(video, q, iters=1)
+    assert extra is None
+    assert maxdiff(c, g["coords"]) < 1e-3
+    assert maxdiff(logit(v), logit(g["vis"])) < 2e-4
+    m.init_video_online_processing()
+    for ind in range(0, video.shape[1] - 4, 4):
+        cs, vs, _ = m(video[:, ind:ind + 8], q, iters=1, is_online=True)
+    assert maxdiff(cs, g["stream_coords"]) < 1e-3
+    assert maxdiff(logit(vs), logit(g["stream_vis"])) < 2e-4
+
+
+def test_cotracker2_predictor_runs():
+    """hub entry points / predictors with v2=True (hubconf.py:27-45): shapes, dtypes, query-frame fix-up."""
+    from cotracker_amd.predictor import CoTrackerPredictor, CoTrackerOnlinePredictor
+    from cotracker_amd.synthetic import synthetic_video
+    from cotracker_amd.weights import fill_synthetic_
+    video = synthetic_video(12, 96, 128, seed=3).to(dev())
+    p = CoTrackerPredictor(checkpoint=None, v2=True, window_len=8)
+    fill_synthetic_(p.model, seed=2, head_scale=1.0)
+    p = p.to(dev())
+    tr, vi = p(video, grid_size=4)
+    assert tr.shape == (1, 12, 16, 2) and vi.shape == (1, 12, 16) and vi.dtype == torch.bool and torch.isfinite(tr).all()
+    po = CoTrackerOnlinePredictor(checkpoint=None, v2=True, window_len=8)
+    fill_synthetic_(po.model, seed=2, head_scale=1.0)
+    po = po.to(dev())
+    po(video_chunk=video[:, :8], is_first_step=True, grid_size=3)
+    for ind in range(0, 12 - po.step, po.step):
+        tr, vi = po(video_chunk=video[:, ind:ind + 2 * po.step])
+    assert tr.shape[0] == 1 and tr.shape[2] == 9 and tr.shape[3] == 2 and vi.dtype == torch.bool
