@@ -41,6 +41,10 @@ WORKLOADS = {
     "c4_online": (512, 512, 0, 32, False, 16, "512x512 cotracker3_online streaming, 16-frame chunks advancing 8, N=1024, "
                   "window replayed as ONE hipGraph per chunk (BASELINE.json configs[3])"),
     "tiny": (128, 160, 24, 8, False, 8, "smoke-sized"),
+    # CoTracker2 (hub entry point cotracker2: window 8, sliding) on the configs[2] video -- not a BASELINE config, the
+    # measured line of SURVEY 8f-3
+    "v2_sliding": (512, 512, 120, 80, "v2", 8, "512x512 T=120 N=6400 cotracker2 (window 8, sliding): CorrBlock sampler + "
+                   "6+6-layer update former with attention masks on the same kernels"),
 }
 
 
@@ -208,6 +212,8 @@ def main():
         pred = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
         pred.model.hip_graph = not args.no_graph
         T = pred.step * (args.steps + args.warmup + 3)  # one chunk call per step, plus the profiled call
+    elif offline == "v2":
+        pred = CoTrackerPredictor(checkpoint=None, v2=True, window_len=wl)
     else:
         pred = CoTrackerPredictor(checkpoint=None, offline=offline, window_len=wl)
     fill_synthetic_(pred.model, seed=0)
@@ -270,7 +276,7 @@ def main():
         "dtype": "f32 (Linear layers as split-half f16 MFMA x3, f32 accumulate)" if args.precision == "f16x3" else "f32",
         "data": "synthetic",
         "config": {"workload": desc, "name": args.workload, "points_per_gpu": N, "frames": frames_per_step, "video": [H, W],
-                   "iters": 6, "window_len": wl, "offline": offline, "sharding": f"points x{world}", "precision": args.precision,
+                   "iters": 6, "window_len": wl, "offline": bool(offline) and offline != "v2", "sharding": f"points x{world}", "precision": args.precision,
                    "weights": "seeded synthetic (no checkpoints offline)"},
     }
     if streaming:
@@ -313,11 +319,11 @@ def main():
         result["parity"] = parity_probe(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         overlap = 1.0
-        if not offline:
+        if not offline or offline == "v2":
             S, step_ = wl, wl // 2
             nwin = (T - S + step_ - 1) // step_ + 1
             overlap = nwin * S / T
-        result["cpu_baseline"] = cpu_baseline(16 if not offline else 16, overlap)
+        result["cpu_baseline"] = cpu_baseline(16 if not offline else 16, overlap)  # CoTracker3 update path sample
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -33,6 +33,18 @@ def main(d, out):
         for r in rows[:25]:
             lines.append(f"{short(r['Name']):72s} {r['Calls']:>8s} {float(r['TotalDurationNs']) / 1e6:10.2f} "
                          f"{float(r['AverageNs']) / 1e3:10.1f} {float(r['Percentage']):6.2f}")
+        # library kernels grouped under the names of bench.py's HIP-event recorder (template instantiations of one
+        # kernel -- e.g. the compile-time GEMM epilogues -- are separate rocprof rows): call-weighted mean duration
+        grp = defaultdict(lambda: [0, 0.0])
+        for r in rows:
+            for pat, nm in NAME_MAP:
+                if pat in r["Name"]:
+                    grp[nm][0] += int(r["Calls"])
+                    grp[nm][1] += float(r["TotalDurationNs"])
+                    break
+        lines.append("-- grouped by recorder name (compare with bench.py \"kernels\"[].avg_us)")
+        for nm, (n, t) in sorted(grp.items(), key=lambda kv: -kv[1][1]):
+            lines.append(f"{nm:72s} {n:8d} {t / 1e6:10.2f} {t / max(n, 1) / 1e3:10.1f}")
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         lines.append(f"== {os.path.relpath(f, d)} (per-kernel counter means)")
         agg = defaultdict(lambda: [0, 0.0])
