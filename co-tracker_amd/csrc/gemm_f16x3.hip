@@ -496,7 +496,7 @@ __global__ void weight_pack_kernel(const float* W, long ldw, int N, int K, const
 
 namespace {
 // Dev knob (read per call): CTK_GEMM_TILE = 0 auto (128x128, 2 blocks/CU) | 2 force 256x128 (8 waves, 1 block/CU,
-// 2 LDS stages) | 3 force 256x128 with 3 LDS stages (counted vmcnt + raw barrier).
+// 2 LDS stages) | 3 force 256x128 with 3 LDS stages (counted vmcnt + raw barrier) | 4 use 128x384 for N = 384.
 int gemm_tile_pref() {
   const char* e = getenv("CTK_GEMM_TILE");
   return e ? atoi(e) : 0;
@@ -515,7 +515,22 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
   const bool big = (g.N % 128) == 0 && blocks128 >= 384;
   if (g.a_split) {
     const int pref = gemm_tile_pref();
-    if (big && pref == 3) {
+    // 128x384 tile (8 waves as 2 x 4, each 64 x 96): the block owns full rows of an N = 384 Linear, A is fetched once
+    // instead of three times and a wave issues 1.6 instead of 3.2 non-MFMA instructions per MFMA.  Opt-in only
+    // (CTK_GEMM_TILE=4): for corr_mlp.fc1 it is 6 % faster in tools/bench_gemm.py (2.62 -> 2.47 ms) but slower inside
+    // the update iteration (2.49 ms per launch, +25 ms per C3 step) -- one 8-wave block per CU starts cold behind
+    // the sampler where two 4-wave blocks overlap their prologues.
+    const long rows128 = (g.M + 127) / 128;
+    if (g.N == 384 && g.batch == 1 && pref == 4) {
+      g.mblocks = (int)rows128; g.nblocks = 1;
+      CtkProfScope ps("gemm_sh_128x384", flops, bytes, s);
+      const int code = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
+      const dim3 grid((unsigned)rows128), blk(512);
+      if (code == epi_code(CTK_ACT_GELU_ERF, false, true, false, true))
+        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 2, 3, 2, epi_code(CTK_ACT_GELU_ERF, false, true, false, true)>), grid, blk, 0, s, g);
+      else
+        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 2, 3, 2, EPI_GENERIC>), grid, blk, 0, s, g);
+    } else if (big && pref == 3) {
       g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 128;
       CtkProfScope ps("gemm_sh_256x128x3", flops, bytes, s);
       hipLaunchKernelGGL((gemm_sh_kernel<4, 2, 2, 2, 3>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(512), 0, s, g);

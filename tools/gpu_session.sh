@@ -15,9 +15,11 @@ if has bench; then
   (timeout 300 python bench.py --workload c4_online --steps 12 --warmup 3 --no-cpu-baseline 2>gpurun_out/bench_c4.err | tail -1) > gpurun_out/bench_c4_graph.json
   (timeout 300 python bench.py --workload c4_online --steps 12 --warmup 3 --no-cpu-baseline --no-graph --no-profile 2>>gpurun_out/bench_c4.err | tail -1) > gpurun_out/bench_c4_nograph.json
   (timeout 300 python bench.py --workload c2_offline --steps 5 --warmup 2 --no-cpu-baseline 2>gpurun_out/bench_c2.err | tail -1) > gpurun_out/bench_c2.json
+  (timeout 300 python bench.py --workload c3_offline --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/bench_c3off.err | tail -1) > gpurun_out/bench_c3_offline.json
+  (timeout 300 python bench.py --workload v2_sliding --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/bench_v2.err | tail -1) > gpurun_out/bench_v2_sliding.json
   python - <<'PY'
 import json
-for f in ("bench_c3", "bench_c4_graph", "bench_c4_nograph", "bench_c2"):
+for f in ("bench_c3", "bench_c4_graph", "bench_c4_nograph", "bench_c2", "bench_c3_offline", "bench_v2_sliding"):
     try:
         d = json.load(open(f"gpurun_out/{f}.json"))
         print(f, d["value"], d["ms_per_step"], d.get("parity"), d.get("cpu_baseline", {}).get("value"))
