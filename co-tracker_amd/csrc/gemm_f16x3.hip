@@ -496,7 +496,8 @@ __global__ void weight_pack_kernel(const float* W, long ldw, int N, int K, const
 
 namespace {
 // Dev knob (read per call): CTK_GEMM_TILE = 0 auto (128x128, 2 blocks/CU) | 2 force 256x128 (8 waves, 1 block/CU,
-// 2 LDS stages) | 3 force 256x128 with 3 LDS stages (counted vmcnt + raw barrier) | 4 use 128x384 for N = 384.
+// 2 LDS stages) | 3 force 256x128 with 3 LDS stages (counted vmcnt + raw barrier) | 4 use 128x384 for N = 384 | 5 64x128 tile (3 workgroups per CU) | 6 256x256 tile for every N % 256 == 0 launch |
+// 1 128x128 everywhere (no 256x256).
 int gemm_tile_pref() {
   const char* e = getenv("CTK_GEMM_TILE");
   return e ? atoi(e) : 0;
@@ -521,7 +522,27 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
     // the update iteration (2.49 ms per launch, +25 ms per C3 step) -- one 8-wave block per CU starts cold behind
     // the sampler where two 4-wave blocks overlap their prologues.
     const long rows128 = (g.M + 127) / 128;
-    if (g.N == 384 && g.batch == 1 && pref == 4) {
+    const int code256 = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
+    const bool epi256 = code256 == epi_code(CTK_ACT_NONE, false, false, false, true) ||      // to_kv
+                        code256 == epi_code(CTK_ACT_GELU_TANH, false, true, false, true) ||  // mlp.fc1
+                        code256 == epi_code(CTK_ACT_NONE, false, true, false, true);         // corr_mlp.fc2
+    const long blocks256 = (long)((g.M + 255) / 256) * (g.N / 256) * g.batch;  // one 8-wave block per CU: want >= 2 rounds
+    if (big && (g.N % 256) == 0 && blocks256 >= 512 && pref != 1 && (pref == 6 || epi256)) {
+      // 256x256 tile, 8 waves as 2 x 4, wave tile 128 x 64: 48 MFMAs per 24 fragment reads (128x128: 24 per 16).
+      // Default for the N % 256 == 0 Linears that have a compile-time epilogue (to_kv, mlp.fc1, corr_mlp.fc2):
+      // -5..-11 % per launch in tools/bench_gemm.py, -0.6 % per C3 step measured in situ.  CTK_GEMM_TILE=1 disables.
+      g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 256;
+      CtkProfScope ps("gemm_sh_256x256", flops, bytes, s);
+      const dim3 grid((unsigned)((long)g.mblocks * g.nblocks * g.batch)), blk(512);
+      if (code256 == epi_code(CTK_ACT_NONE, false, false, false, true))
+        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 4, 2, 2, epi_code(CTK_ACT_NONE, false, false, false, true)>), grid, blk, 0, s, g);
+      else if (code256 == epi_code(CTK_ACT_GELU_TANH, false, true, false, true))
+        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 4, 2, 2, epi_code(CTK_ACT_GELU_TANH, false, true, false, true)>), grid, blk, 0, s, g);
+      else if (code256 == epi_code(CTK_ACT_NONE, false, true, false, true))
+        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 4, 2, 2, epi_code(CTK_ACT_NONE, false, true, false, true)>), grid, blk, 0, s, g);
+      else
+        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 4, 2, 2, EPI_GENERIC>), grid, blk, 0, s, g);
+    } else if (g.N == 384 && g.batch == 1 && pref == 4) {
       g.mblocks = (int)rows128; g.nblocks = 1;
       CtkProfScope ps("gemm_sh_128x384", flops, bytes, s);
       const int code = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
@@ -540,11 +561,18 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
       hipLaunchKernelGGL((gemm_sh_kernel<4, 2, 2, 2, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(512), 0, s, g);
     } else if (big) {
       g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;
-      CtkProfScope ps("gemm_sh_128x128", flops, bytes, s);
       // the six flag combinations of the update path get compile-time epilogues; anything else the generic one
       const int code = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
-      const dim3 grid((unsigned)blocks128), blk(256);
-#define CTK_SH128(E) hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2, 2, E>), grid, blk, 0, s, g)
+      // CTK_GEMM_TILE=5: 64x128 tile (wave 32x64, 48 KB of LDS -> three workgroups per CU instead of two)
+      const bool t64 = pref == 5;
+      if (t64) { g.mblocks = (g.M + 63) / 64; }
+      CtkProfScope ps(t64 ? "gemm_sh_64x128" : "gemm_sh_128x128", flops, bytes, s);
+      const dim3 grid((unsigned)((long)g.mblocks * g.nblocks * g.batch)), blk(256);
+#define CTK_SH128(E)                                                                     \
+  do {                                                                                   \
+    if (t64) hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 2, 2, E>), grid, blk, 0, s, g); \
+    else hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2, 2, E>), grid, blk, 0, s, g);     \
+  } while (0)
       const char* ge = getenv("CTK_GEMM_EPI");  // dev knob: CTK_GEMM_EPI=0 forces the generic epilogue
       if (ge && atoi(ge) == 0) CTK_SH128(EPI_GENERIC);
       else switch (code) {

@@ -17,6 +17,7 @@ import sys
 
 NAME_MAP = [
     (r"gemm_sh_kernel<2, 4, 2, 3,", "gemm_sh_128x384"),
+    (r"gemm_sh_kernel<2, 4, 4, 2,", "gemm_sh_256x256"),
     (r"gemm_sh_kernel<2, 2, 2, 2,", "gemm_sh_128x128"),
     (r"gemm_sh_kernel<4, 2, 2, 2, 3", "gemm_sh_256x128x3"),
     (r"gemm_sh_kernel<4, 2, 2, 2,", "gemm_sh_256x128"),
