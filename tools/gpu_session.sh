@@ -40,8 +40,8 @@ if has prof; then
   (cd $R && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- $CMD0 > $R/gpurun_out/prof_write.log 2>&1)
   cd $R
   python tools/summarize_rocprof.py gpurun_out/prof_stats gpurun_out/rocprof_kernel_stats.txt | head -30
-  F=$(find gpurun_out/prof_fetch -name '*counter_collection.csv' | head -1)
-  W=$(find gpurun_out/prof_write -name '*counter_collection.csv' | head -1)
+  F=$(ls -t $(find gpurun_out/prof_fetch -name "*counter_collection.csv") | head -1)
+  W=$(ls -t $(find gpurun_out/prof_write -name "*counter_collection.csv") | head -1)
   python tools/pmc_traffic.py "$F" "$W" gpurun_out/pmc_traffic.json
   # keep only the small summaries (raw traces are large)
   find gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write -name '*kernel_trace.csv' -delete
