@@ -6,48 +6,53 @@
 
 namespace {
 
-// ---- LayerNorm over 384 channels: one wavefront per row, 6 values per lane ----------------
+// ---- LayerNorm over 384 channels: one HALF-wave (32 lanes) per row, 3 float4 per lane ------------
 // nn.LayerNorm(384, elementwise_affine=False, eps=1e-6)  blocks.py:411,416 / cotracker.py:539,549
 // nn.LayerNorm(384) (affine, eps=1e-5)                    cotracker.py:540 (norm_context)
+// 16-byte loads, 16-byte f32 / 8-byte SH stores (the earlier wave-per-row version moved 8 / 4 bytes per lane);
+// the two-pass mean / variance is unchanged.
+__device__ __forceinline__ float ctk_half_sum(float v) {  // sum over the 32 lanes of my half-wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y, long R, const float* gamma,
                                                          const float* beta, float eps, int out_split) {
-  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (row >= R) return;
-  const float* xr = x + row * CTK_HID;
-  float2 v[3];
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int j = threadIdx.x & 31;
+  if (row >= R) return;  // whole half-waves leave together (xor-shuffles stay inside a half)
+  const float* xr = x + row * CTK_HID + 4 * j;
+  f32x4 v[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const float2*>(xr + j * 128 + lane * 2);
+  for (int k = 0; k < 3; ++k) v[k] = *reinterpret_cast<const f32x4*>(xr + 128 * k);
   float s = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s += v[j].x + v[j].y;
-  const float mean = ctk_wave_sum(s) * (1.0f / CTK_HID);
+  for (int k = 0; k < 3; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  const float mean = ctk_half_sum(s) * (1.0f / CTK_HID);
   float q = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    v[j].x -= mean;
-    v[j].y -= mean;
-    q += v[j].x * v[j].x + v[j].y * v[j].y;
+  for (int k = 0; k < 3; ++k) {
+    v[k] -= mean;
+    q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
   }
-  const float var = ctk_wave_sum(q) * (1.0f / CTK_HID);
+  const float var = ctk_half_sum(q) * (1.0f / CTK_HID);
   const float rstd = 1.0f / sqrtf(var + eps);
-  float* yr = y + row * CTK_HID;
+  float* yr = y + row * CTK_HID + 4 * j;
   _Float16* yh = reinterpret_cast<_Float16*>(y) + row * (2 * CTK_HID);  // SH row: 12 tiles x 64 halves
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int c = j * 128 + lane * 2;
-    float2 o = make_float2(v[j].x * rstd, v[j].y * rstd);
-    if (gamma) {
-      o.x = o.x * gamma[c] + beta[c];
-      o.y = o.y * gamma[c + 1] + beta[c + 1];
-    }
+  for (int k = 0; k < 3; ++k) {
+    const int c = 128 * k + 4 * j;
+    f32x4 o = v[k] * rstd;
+    if (gamma) o = o * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
     if (out_split) {
-      f16x2 hi, lo;
-      ctk_split2(f32x2{o.x, o.y}, hi, lo);
-      *reinterpret_cast<f16x2*>(yh + ctk_sh_col(c)) = hi;
-      *reinterpret_cast<f16x2*>(yh + ctk_sh_col(c) + 32) = lo;
+      f16x4 hi, lo;
+      ctk_split4(o, hi, lo);
+      _Float16* dst = yh + ctk_sh_col(c);
+      *reinterpret_cast<f16x4*>(dst) = hi;
+      *reinterpret_cast<f16x4*>(dst + 32) = lo;
     } else {
-      *reinterpret_cast<float2*>(yr + c) = o;
+      *reinterpret_cast<f32x4*>(yr + 128 * k) = o;
     }
   }
 }
@@ -160,7 +165,7 @@ extern "C" int ctk_layernorm(const float* x, void* y, int64_t R, const float* ga
   if (R <= 0) return CTK_E_SHAPE;
   if ((gamma == nullptr) != (beta == nullptr)) return CTK_E_NULL;
   CtkProfScope ps("layernorm", 8.0 * R * CTK_HID, 8.0 * R * CTK_HID, static_cast<hipStream_t>(stream));
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      static_cast<float*>(y), (long)R, gamma, beta, eps, out_split);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
