@@ -69,7 +69,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(window_len, overlap_factor, iters=6):
+def cpu_baseline(window_len, overlap_factor, iters=6, n_points=96, reps=2):
     """Numpy oracle (oracle/, kind="port") on a bounded sample of the same workload: one S=16 window,
     N=96 points on a 96x128 pyramid, 1 update iteration.  Encoder excluded (update path only)."""
     import numpy as np
@@ -81,7 +81,7 @@ def cpu_baseline(window_len, overlap_factor, iters=6):
     fill_synthetic_(m, seed=0)
     p = {k: v.numpy() for k, v in m.state_dict().items() if not k.startswith("fnet.")}
     r = np.random.RandomState(0)
-    S, N = window_len, 96
+    S, N = window_len, n_points
     f = r.standard_normal((1, S, 128, 96, 128)).astype(np.float32)
     pyr = O.build_pyramid(O.normalize_fmaps(f))
     qc = (r.uniform(0, 1, size=(1, N, 2)) * np.array([127, 95])).astype(np.float32)
@@ -89,7 +89,6 @@ def cpu_baseline(window_len, overlap_factor, iters=6):
            for i in range(4)]
     c = np.broadcast_to(qc.reshape(1, 1, N, 2), (1, S, N, 2)).astype(np.float32)
     z = np.zeros((1, S, N, 1), np.float32)
-    reps = 2
     t0 = time.time()
     for _ in range(reps):
         O.forward_window(pyr, c, sup, z, z, p, iters=1)
