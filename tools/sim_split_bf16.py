@@ -1,7 +1,9 @@
 """Numerics study (CPU, build container): what does replacing every exact-f32 Linear of the update
 path by a split-bf16 contraction (a = a_hi + a_lo, 3 bf16 MFMAs: hi*hi + hi*lo + lo*hi, f32
 accumulate) cost against the reference goldens?  Uses the numpy oracle as the harness (this is a
-tool, not product code).  Usage: python tools/sim_split_bf16.py [terms]   terms in {1,3,6}; optional 2nd arg f16 = split into IEEE half instead of bf16"""
+tool, not product code).  Usage: python tools/sim_split_bf16.py [terms]   terms in {1,3,6}; optional 2nd arg f16 = split into IEEE half instead of bf16.
+Two-term study (3rd arg): "2a:<min_k>" drops the hi_w*lo_a term (activations rounded to one half) and "2w:<min_k>" the
+lo_w*hi_a term (weights rounded to one half) in every Linear whose K (input width) is >= min_k; the others keep 3 terms."""
 import os
 import sys
 
@@ -18,6 +20,7 @@ TERMS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 
 
 DT = torch.float16 if (len(sys.argv) > 2 and sys.argv[2] == "f16") else torch.bfloat16
+TWO = sys.argv[3].split(":") if len(sys.argv) > 3 else None   # e.g. ["2a", "1536"]
 
 
 def split(x, n):
@@ -37,7 +40,10 @@ def linear_split(x, w, b=None):
         y = xa[0] @ wa[0].T
     elif TERMS == 3:
         xa, wa = split(x2, 2), split(w, 2)
-        y = xa[1] @ wa[0].T + xa[0] @ wa[1].T + xa[0] @ wa[0].T
+        if TWO is not None and w.shape[1] >= int(TWO[1]) and (len(TWO) < 3 or w.shape[1] <= int(TWO[2])):
+            y = (xa[0] @ wa[1].T if TWO[0] == "2a" else xa[1] @ wa[0].T) + xa[0] @ wa[0].T
+        else:
+            y = xa[1] @ wa[0].T + xa[0] @ wa[1].T + xa[0] @ wa[0].T
     else:
         xa, wa = split(x2, 3), split(w, 3)
         y = (xa[2] @ wa[0].T + xa[0] @ wa[2].T + xa[1] @ wa[1].T) + (xa[1] @ wa[0].T + xa[0] @ wa[1].T) + xa[0] @ wa[0].T
