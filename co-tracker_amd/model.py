@@ -14,7 +14,6 @@ assembly, EfficientUpdateFormer, state update) runs in the HIP library through
 ``cotracker_amd.ops``.  Window scheduling and online state are Python glue, as in the reference.
 Inference only (``is_train`` must be False).
 """
-import math
 from typing import List, Optional
 
 import torch

@@ -5,7 +5,6 @@ import ctypes as C
 import os
 import re
 
-import numpy as np
 import pytest
 import torch
 

@@ -2,7 +2,6 @@
 made by tests/golden/make_golden.py with torch 2.10.0+rocm7.0 on CPU)."""
 import numpy as np
 import pytest
-import torch
 
 from oracle import cotracker_oracle as O
 from cotracker_amd.weights import synthetic_tensor

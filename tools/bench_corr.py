@@ -4,7 +4,6 @@ Version 1 (default) vs version 2 (CTK_CORR=2) and its bisection bits (CTK_CORR_D
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

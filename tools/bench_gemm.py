@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cotracker_amd import ops, _lib as L  # noqa: E402
+from cotracker_amd import ops  # noqa: E402
 
 P, V = 6400 * 16, 64 * 16
 R = P + V
