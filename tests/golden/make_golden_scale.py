@@ -1,0 +1,125 @@
+"""Goldens at BASELINE.json scale: the UNMODIFIED reference on CPU fp32 at the real 384x512 model resolution.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden_scale.py c2 c4 c3_g40 c3_g80      # any subset, in this order of cost
+
+Workloads are bench.py's (same synthetic video seed 1234, same ``fill_synthetic_(seed=0)`` weights):
+  c2      BASELINE configs[1]: CoTrackerPredictor(offline=True, window_len=60), 256x256, T=48, grid 20 (N=400)
+  c4      BASELINE configs[3]: CoTrackerOnlinePredictor(window_len=16), 512x512, grid 32 (N=1024), 5 chunk calls (T=48)
+  c3_g40  BASELINE configs[2] video (512x512, T=120), CoTrackerPredictor(offline=False, window_len=16), grid 40 (N=1600)
+  c3_g80  BASELINE configs[2] exactly: grid 80 (N=6400), 14 windows x 6 iterations, jointly tracked
+Stored per workload (OUTPUTS ONLY -- inputs and weights are regenerated from seeds on both sides):
+  coords  [T,N,2]  model-level tracks in model-resolution pixels (model.forward()[0])
+  vis_logit / conf_logit [T,N]  PRE-sigmoid (the argument of the reference's own torch.sigmoid call, captured by wrapping
+          torch.sigmoid while the reference runs; the reference source is not touched)
+  tracks  [T,N,2] / vis [T,N] bool   predictor-level outputs (raw-video pixels, thresholded visibility)
+  noise_* the same run with a different intra-op thread count (the reference's own reduction-order noise floor):
+          max |a-b| over coords (px) / logits, plus its 99.9th percentile
+  threads, noise_threads, seconds, torch version.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from cotracker.predictor import CoTrackerPredictor, CoTrackerOnlinePredictor  # noqa: E402
+
+from cotracker_amd.weights import fill_synthetic_  # noqa: E402
+from cotracker_amd.synthetic import synthetic_video  # noqa: E402
+
+CONFIGS = {
+    # name: (H, W, T, grid, kind, window_len, threads, noise_threads)
+    "c2": (256, 256, 48, 20, "offline", 60, 8, 1),
+    "c4": (512, 512, 48, 32, "online", 16, 8, 3),
+    "c3_g40": (512, 512, 120, 40, "sliding", 16, 8, 3),
+    "c3_g80": (512, 512, 120, 80, "sliding", 16, 8, 5),
+}
+
+
+class SigmoidTap:
+    """Records the arguments of torch.sigmoid while active (the reference applies it to the final logits:
+    cotracker3_online.py:524-525, cotracker3_offline.py:215-216)."""
+
+    def __enter__(self):
+        self.args = []
+        self.orig = torch.sigmoid
+
+        def tapped(x):
+            self.args.append(x.detach().clone())
+            return self.orig(x)
+
+        torch.sigmoid = tapped
+        return self
+
+    def __exit__(self, *a):
+        torch.sigmoid = self.orig
+
+
+@torch.no_grad()
+def run(name, threads):
+    H, W, T, G, kind, wl, _, _ = CONFIGS[name]
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    video = synthetic_video(T, H, W, seed=1234)
+    captured = {}
+    if kind == "online":
+        p = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
+    else:
+        p = CoTrackerPredictor(checkpoint=None, offline=(kind == "offline"), window_len=wl)
+    fill_synthetic_(p.model, seed=0)
+    model_forward = p.model.forward
+
+    def tap_forward(*a, **k):
+        out = model_forward(*a, **k)
+        captured["coords"] = out[0].detach().clone()
+        return out
+
+    p.model.forward = tap_forward
+    t0 = time.time()
+    with SigmoidTap() as tap:
+        if kind == "online":
+            p(video_chunk=video[:, :2 * p.step], is_first_step=True, grid_size=G)
+            for ind in range(0, T - p.step, p.step):
+                tracks, vis = p(video_chunk=video[:, ind: ind + 2 * p.step])
+        else:
+            tracks, vis = p(video, grid_size=G)
+    dt = time.time() - t0
+    vis_logit, conf_logit = tap.args[-2], tap.args[-1]  # the last two sigmoid calls are the returned vis / conf
+    out = dict(coords=captured["coords"][0], vis_logit=vis_logit[0].reshape(vis_logit.shape[1], -1),
+               conf_logit=conf_logit[0].reshape(conf_logit.shape[1], -1), tracks=tracks[0], vis=vis[0])
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    print(f"{name}: threads={threads} {dt:.1f} s  {T * G * G / dt:.1f} tracked-point-frames/s", flush=True)
+    return out, dt
+
+
+def main():
+    for name in sys.argv[1:]:
+        _, _, T, G, kind, wl, th, nth = CONFIGS[name]
+        a, dt = run(name, th)
+        b, dtn = run(name, nth)
+        stats = {}
+        for k in ("coords", "vis_logit", "conf_logit"):
+            d = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64))
+            stats[f"noise_{k}_max"] = d.max()
+            stats[f"noise_{k}_p999"] = np.quantile(d, 0.999)
+            stats[f"noise_{k}_median"] = np.median(d)
+        stats["noise_vis_flips"] = int((a["vis"] != b["vis"]).sum())
+        print(name, {k: float(v) for k, v in stats.items()}, flush=True)
+        path = os.path.join(HERE, f"scale_{name}.npz")
+        np.savez_compressed(path, **a, **stats, threads=th, noise_threads=nth, seconds=dt, noise_seconds=dtn,
+                            host_cpus=os.cpu_count(),
+                            meta=np.array(f"torch {torch.__version__}; facebookresearch/co-tracker@2025-03-04; "
+                                          f"{kind} window_len={wl} grid={G} T={T}"))
+        print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
+if __name__ == "__main__":
+    main()
