@@ -14,6 +14,7 @@ assembly, EfficientUpdateFormer, state update) runs in the HIP library through
 ``cotracker_amd.ops``.  Window scheduling and online state are Python glue, as in the reference.
 Inference only (``is_train`` must be False).
 """
+import warnings
 from typing import List, Optional
 
 import torch
@@ -209,7 +210,7 @@ class CoTrackerThreeBase(nn.Module):
         if (corr_radius, corr_levels, num_virtual_tracks) != (3, 4, 64) or not add_space_attn \
                 or not linear_layer_for_vis_conf:
             raise NotImplementedError("HIP path is specialised to corr_radius=3, corr_levels=4, 64 virtual tracks, "
-                                      "space attention on (build_cotracker.py:31-38)")
+                                      "space attention on (build_cotracker.py:31-38); see INTEGRATION.md")
         self.window_len = window_len
         self.stride = stride
         self.corr_radius = corr_radius
@@ -224,7 +225,7 @@ class CoTrackerThreeBase(nn.Module):
         self.updateformer = _UpdateFormerParams(self.input_dim, 384, 3, num_virtual_tracks)
         self.corr_mlp = _Mlp(49 * 49, 384, 256)
         self.register_buffer("time_emb", sincos_time_embed(self.input_dim, window_len))
-        self._packed: Optional[PackedWeights] = None
+        self._packed = {}  # precision -> PackedWeights
         self.max_corr_rows = 262144  # (point,frame) rows of correlation volume resident at once (~10 GB)
         # arithmetic of the Linear layers: "f16x3" = split-half MFMA (3 f16 MFMAs per product, f32 accumulate,
         # fp32-class accuracy at 5.3x the f32-MFMA ceiling), "f32" = exact-f32 MFMA.  Not a reference kwarg.
@@ -234,6 +235,14 @@ class CoTrackerThreeBase(nn.Module):
         # per chunk.  Not a reference kwarg; CoTrackerOnlinePredictor switches it on.
         self.hip_graph = False
         self._graphs = {}
+        # f16 range guard of the split-half back end (include/ctk.h "numeric range"): an activation beyond +-65504
+        # becomes inf/NaN in its hi/lo halves and reaches the window state as a non-finite value (nothing on the path
+        # clamps or masks it), so every forward checks its outputs once and, on a hit, re-runs that forward on the
+        # exact-f32 MFMA back end of the same library (fp32 range, as the reference).  range_fallbacks counts hits.
+        self.range_guard = True
+        self.range_fallbacks = 0
+        # pre-sigmoid (visibility, confidence) of the last forward, [B,T,N] each -- parity tests compare logits
+        self.last_logits = None
 
     # -- weights ------------------------------------------------------------------------
     def load_state_dict(self, *args, **kwargs):
@@ -244,30 +253,72 @@ class CoTrackerThreeBase(nn.Module):
         self.invalidate_packed_weights()
         return super()._apply(fn, *args, **kwargs)
 
-    def packed(self, device) -> PackedWeights:
-        if self._packed is None or self._packed.device != device or self._packed.precision != self.precision:
-            self._packed = PackedWeights(self, device, self.precision)
-        return self._packed
+    def packed(self, device, precision: Optional[str] = None) -> PackedWeights:
+        precision = precision or self.precision
+        pw = self._packed.get(precision)
+        if pw is None or pw.device != device:
+            pw = self._packed[precision] = PackedWeights(self, device, precision)
+        return pw
 
     def invalidate_packed_weights(self):
         """Call after mutating parameters in place (e.g. weights.fill_synthetic_)."""
-        self._packed = None
+        self._packed = {}
+        self._drop_graphs()  # captured graphs hold pointers into the old packed weights
+
+    def _drop_graphs(self):
         if getattr(self, "_graphs", None):
-            self._graphs = {}  # captured graphs hold pointers into the old packed weights
+            # a replay may still be in flight on the current stream: destroying the exec / freeing its private
+            # workspace under it is undefined, so drain first
+            if torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()
+            self._graphs = {}
+
+    # device-side caches (ctypes structs with raw pointers) are rebuilt on demand: keep them out of pickles / deep copies
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_packed"] = {}
+        st["_graphs"] = {}
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k in ("_packed", "_graphs") else copy.deepcopy(v, memo)
+        return new
+
+    def _guarded(self, run, snapshot=None, restore=None):
+        """run(precision) -> (coords, vis_logit, conf_logit) under the f16 range guard described in __init__."""
+        out = run(self.precision)
+        if self.precision == "f16x3" and self.range_guard:
+            finite = torch.stack([torch.isfinite(o).all() for o in out]).all()
+            if not bool(finite):
+                self.range_fallbacks += 1
+                warnings.warn("cotracker_amd: non-finite tracks from the split-half (f16x3) back end -- an activation left "
+                              "the f16 range (|x| < 65504) or the input is non-finite; re-running this forward on the "
+                              "exact-f32 MFMA back end", RuntimeWarning, stacklevel=3)
+                if restore is not None:
+                    restore(snapshot)
+                out = run("f32")
+        return out
 
     def _graphed_window(self, fm, support, coords, vis, conf, mask, iters, pw):
         """Run one window through its captured hipGraph: static buffers are created (and the graph captured) on
         first use of this (shapes, iters, weights) combination, then only refreshed in place and replayed.
         Returns the static coords/vis/conf tensors (overwritten by the next call)."""
-        key = (tuple(tuple(f.shape) for f in fm), coords.shape[1], int(iters), id(pw), coords.device.index)
+        key = (tuple(tuple(f.shape) for f in fm), coords.shape[1], int(iters), id(pw), coords.device.index,
+               int(self.max_corr_rows), tuple(self.model_resolution), int(self.stride))
         g = self._graphs.get(key)
         if g is None:
             st_fm = [f.clone() for f in fm]
             st_sup = [s_.clone() for s_ in support]
             win = ops.Window(st_fm, st_sup, coords.clone(), vis.clone(), conf.clone(), self._scale_xy(), iters=iters,
                              point_mask=mask.clone(), max_corr_rows=self.max_corr_rows)
+            self._drop_graphs()  # one live graph per model: a new shape replaces the old one (frees its workspace)
             g = ops.WindowGraph(win, pw)
-            self._graphs = {key: g}  # one live graph per model: a new shape replaces the old one (frees its workspace)
+            self._graphs = {key: g}
         else:
             st_fm, st_sup, c_, v_, f_, m_ = g.win.keep
             for d, s_ in zip(st_fm, fm):
@@ -296,9 +347,12 @@ class CoTrackerThreeBase(nn.Module):
     def _support(self, pyr, frames_f: torch.Tensor, qcoords: torch.Tensor):
         return [ops.sample_support(pyr[l], frames_f, (qcoords / 2 ** l).contiguous()) for l in range(self.corr_levels)]
 
-    def _check_inputs(self, video, queries, is_train):
+    def _check_inputs(self, video, queries, is_train, add_space_attn=True):
         if is_train:
             raise NotImplementedError("inference-only implementation (training is out of scope)")
+        if not add_space_attn:
+            raise NotImplementedError("add_space_attn=False is not built: the HIP update former always runs the "
+                                      "virtual-track space attention (cotracker.py:499-519)")
         if not video.is_cuda:
             raise RuntimeError("cotracker_amd runs on an MI355X GPU only: move the model and inputs to 'cuda'. "
                                "There is no CPU path.")
@@ -322,7 +376,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
     @torch.no_grad()
     def forward(self, video, queries, iters=4, is_train=False, add_space_attn=True, fmaps_chunk_size=200,
                 is_online=False):
-        B, T, H, W = self._check_inputs(video, queries, is_train)
+        B, T, H, W = self._check_inputs(video, queries, is_train, add_space_attn)
         S = self.window_len
         assert S >= 2
         if is_online:
@@ -330,19 +384,31 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
             assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
         if B != 1 and is_online:
             raise NotImplementedError("online mode supports B=1")
-        outs = [self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, is_online) for b in range(B)]
+        outs = [self._guarded(lambda prec, b=b: self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, is_online, prec),
+                              self._online_snapshot() if is_online else None, self._online_restore) for b in range(B)]
         coords = torch.stack([o[0] for o in outs])
         vis = torch.stack([o[1] for o in outs])
         conf = torch.stack([o[2] for o in outs])
-        return coords, vis, conf, None
+        self.last_logits = (vis, conf)
+        return coords, torch.sigmoid(vis), torch.sigmoid(conf), None
 
-    def _forward_one(self, video, queries, iters, chunk, is_online):
+    def _online_snapshot(self):
+        return (self.online_ind, list(self.online_track_support), self.online_coords_predicted, self.online_vis_predicted,
+                self.online_conf_predicted)
+
+    def _online_restore(self, snap):
+        if snap is not None:
+            (self.online_ind, sup, self.online_coords_predicted, self.online_vis_predicted,
+             self.online_conf_predicted) = snap
+            self.online_track_support = list(sup)
+
+    def _forward_one(self, video, queries, iters, chunk, is_online, precision=None):
         T = video.shape[0]
         N = queries.shape[0]
         S = self.window_len
         step = S // 2
         dev = video.device
-        pw = self.packed(dev)
+        pw = self.packed(dev, precision)
         queries = queries.float()
         qframes = queries[:, 0].long()                      # cotracker3_online.py:333
         qcoords = (queries[:, 1:3] / self.stride).contiguous()  # :335-336
@@ -418,7 +484,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
             self.online_coords_predicted = coords_pred
             self.online_vis_predicted = vis_pred
             self.online_conf_predicted = conf_pred
-        return coords_pred, torch.sigmoid(vis_pred), torch.sigmoid(conf_pred)
+        return coords_pred, vis_pred, conf_pred
 
 
 class CoTrackerThreeOffline(CoTrackerThreeBase):
@@ -426,17 +492,19 @@ class CoTrackerThreeOffline(CoTrackerThreeBase):
 
     @torch.no_grad()
     def forward(self, video, queries, iters=4, is_train=False, add_space_attn=True, fmaps_chunk_size=200):
-        B, T, H, W = self._check_inputs(video, queries, is_train)
+        B, T, H, W = self._check_inputs(video, queries, is_train, add_space_attn)
         assert T >= 1
-        outs = [self._forward_one(video[b], queries[b], iters, fmaps_chunk_size) for b in range(B)]
-        return (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]),
-                torch.stack([o[2] for o in outs]), None)
+        outs = [self._guarded(lambda prec, b=b: self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, prec))
+                for b in range(B)]
+        vis, conf = torch.stack([o[1] for o in outs]), torch.stack([o[2] for o in outs])
+        self.last_logits = (vis, conf)
+        return torch.stack([o[0] for o in outs]), torch.sigmoid(vis), torch.sigmoid(conf), None
 
-    def _forward_one(self, video, queries, iters, chunk):
+    def _forward_one(self, video, queries, iters, chunk, precision=None):
         T = video.shape[0]
         N = queries.shape[0]
         dev = video.device
-        pw = self.packed(dev)
+        pw = self.packed(dev, precision)
         queries = queries.float()
         qframes = queries[:, 0].long()
         qcoords = (queries[:, 1:3] / self.stride).contiguous()
@@ -448,4 +516,4 @@ class CoTrackerThreeOffline(CoTrackerThreeBase):
         win = ops.Window(pyr, support, coords, vis, conf, self._scale_xy(), iters=iters, point_mask=None,
                          max_corr_rows=self.max_corr_rows)
         ops.forward_window(win, pw)
-        return coords * float(self.stride), torch.sigmoid(vis), torch.sigmoid(conf)
+        return coords * float(self.stride), vis, conf

@@ -266,6 +266,23 @@ def _v2_apply(self, fn, *args, **kwargs):
     return nn.Module._apply(self, fn, *args, **kwargs)
 
 
+def _v2_getstate(self):  # the packed-weight cache holds ctypes structs with raw pointers: never pickled / deep-copied
+    st = self.__dict__.copy()
+    st["_packed"] = None
+    return st
+
+
+def _v2_deepcopy(self, memo):
+    import copy
+    new = self.__class__.__new__(self.__class__)
+    memo[id(self)] = new
+    for k, v in self.__dict__.items():
+        new.__dict__[k] = None if k == "_packed" else copy.deepcopy(v, memo)
+    return new
+
+
+CoTracker2.__getstate__ = _v2_getstate
+CoTracker2.__deepcopy__ = _v2_deepcopy
 CoTracker2.forward_window = _v2_forward_window
 CoTracker2.init_video_online_processing = _v2_init_online
 CoTracker2.forward = _v2_forward
