@@ -53,21 +53,34 @@ class CoTrackerPredictor(torch.nn.Module):
                                            add_support_grid=(grid_size == 0 or segm_mask is not None),
                                            grid_query_frame=grid_query_frame, backward_tracking=backward_tracking)
 
-    # dense mode: grid_step^2 independent point chunks (predictor.py:70-98)
-    def _compute_dense_tracks(self, video, grid_query_frame, grid_size=80, backward_tracking=False):
+    # dense mode: grid_step^2 independent point chunks (predictor.py:70-98).  With `dense_group` set (a process group, or
+    # True for the default group) the chunks are dealt out over the ranks and all-gathered (sharding.dense_sharded);
+    # otherwise they are tracked in sequence on this device, as in the reference.
+    dense_group = None
+
+    def _dense_layout(self, video, grid_size=80):
+        H, W = video.shape[-2:]
+        step = W // grid_size  # the reference derives the step from the raw video WIDTH for both axes (predictor.py:73)
+        return step * step, (W // step) * (H // step)
+
+    def _dense_chunk(self, video, offset, grid_query_frame, grid_size=80, backward_tracking=False):
         H, W = video.shape[-2:]
         step = W // grid_size
         gw, gh = W // step, H // step
+        pts = torch.zeros(video.shape[0], gw * gh, 3, device=video.device)
+        pts[:, :, 0] = grid_query_frame
+        pts[:, :, 1] = torch.arange(gw, device=video.device).repeat(gh) * step + offset % step
+        pts[:, :, 2] = torch.arange(gh, device=video.device).repeat_interleave(gw) * step + offset // step
+        return self._compute_sparse_tracks(video=video, queries=pts, backward_tracking=backward_tracking)
+
+    def _compute_dense_tracks(self, video, grid_query_frame, grid_size=80, backward_tracking=False):
+        if self.dense_group is not None:
+            from .sharding import dense_sharded
+            return dense_sharded(self, video, grid_query_frame, grid_size, backward_tracking,
+                                 group=None if self.dense_group is True else self.dense_group)
         tracks = vis = None
-        xs = torch.arange(gw, device=video.device).repeat(gh) * step
-        ys = torch.arange(gh, device=video.device).repeat_interleave(gw) * step
-        for offset in range(step * step):
-            print(f"step {offset} / {step * step}")
-            pts = torch.zeros(video.shape[0], gw * gh, 3, device=video.device)
-            pts[:, :, 0] = grid_query_frame
-            pts[:, :, 1] = xs + offset % step
-            pts[:, :, 2] = ys + offset // step
-            t_step, v_step = self._compute_sparse_tracks(video=video, queries=pts, backward_tracking=backward_tracking)
+        for offset in range(self._dense_layout(video, grid_size)[0]):
+            t_step, v_step = self._dense_chunk(video, offset, grid_query_frame, grid_size, backward_tracking)
             tracks = _cat(tracks, t_step, 2)
             vis = _cat(vis, v_step, 2)
         return tracks, vis

@@ -66,3 +66,33 @@ def track_sharded(predictor, video: torch.Tensor, queries: torch.Tensor, group=N
         tracks = torch.zeros(B, T, 0, 2, device=video.device)
         vis = torch.zeros(B, T, 0, device=video.device, dtype=torch.bool)
     return all_gather_tracks(tracks, vis, queries.shape[1], group)
+
+
+def dense_sharded(predictor, video: torch.Tensor, grid_query_frame: int = 0, grid_size: int = 80,
+                  backward_tracking: bool = False, group=None):
+    """Dense mode (predictor.py:70-98) with its grid_step^2 independent point chunks dealt out over the ranks of
+    `group`: the reference tracks the chunks one after another on one device and concatenates them; here rank r
+    tracks chunks r, r+world, ... with the same per-chunk call (`predictor._dense_chunk`), and ONE fixed-size
+    all_gather per forward puts every chunk on every rank in the reference's chunk order.  Chunks all have the same
+    number of points, so no padding is needed except for ranks that run out of chunks."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_chunks, n_pts = predictor._dense_layout(video, grid_size)
+    B, T = video.shape[:2]
+    per = (n_chunks + world - 1) // world
+    mine = torch.zeros(B, T, per, n_pts, 3, device=video.device, dtype=torch.float32)
+    for j in range(per):
+        c = rank + j * world   # round-robin: every rank has work until the chunks run out
+        if c >= n_chunks:
+            break
+        tr, vi = predictor._dense_chunk(video, c, grid_query_frame, grid_size, backward_tracking)
+        mine[:, :, j, :, :2] = tr
+        mine[:, :, j, :, 2] = vi.to(torch.float32)
+    if world == 1:
+        full = mine
+    else:
+        out = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine, group=group)
+        full = torch.stack(out, dim=3).reshape(B, T, per * world, n_pts, 3)  # index j*world + r == chunk id
+    full = full[:, :, :n_chunks].reshape(B, T, n_chunks * n_pts, 3)
+    return full[..., :2].contiguous(), full[..., 2] > 0.5

@@ -198,6 +198,27 @@ def gen_predictors():
 
 
 @torch.no_grad()
+def gen_predictor_modes():
+    """Dense mode (predictor.py:70-98: queries=None, grid_size=0 -> grid_step^2 independently tracked chunks) and the
+    segm_mask grid filter (predictor.py:131-140)."""
+    import contextlib
+    import io
+    out = {}
+    video = synthetic_video(6, 48, 160, seed=17)  # W=160 -> grid_step 2: 4 chunks of 80 x 24 points
+    torch.manual_seed(0)
+    p = CoTrackerPredictor(checkpoint=None, offline=False, window_len=8)
+    fill_synthetic_(p.model, seed=5)
+    with contextlib.redirect_stdout(io.StringIO()):  # the reference prints "step i / n" per chunk
+        tr, vi = p(video)
+    out.update(dense_video=video, dense_tracks=tr, dense_vis=vi)
+    mask = torch.zeros(1, 1, 48, 160)
+    mask[:, :, 8:40, 30:120] = 1.0
+    tr, vi = p(video, grid_size=12, segm_mask=mask)
+    out.update(segm_mask=mask, segm_tracks=tr, segm_vis=vi)
+    save("predictor_modes.npz", **out)
+
+
+@torch.no_grad()
 def gen_corrblock():
     """CoTracker2's CorrBlock (blocks.py:284-362) and the 4-D bilinear_sampler under it."""
     g = torch.Generator().manual_seed(31)
@@ -275,9 +296,13 @@ def gen_cotracker2():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["predictor_modes"]:
+        gen_predictor_modes()
+        sys.exit(0)
     gen_sampler()
     gen_ops()
     gen_models()
     gen_predictors()
+    gen_predictor_modes()
     gen_corrblock()
     gen_cotracker2()

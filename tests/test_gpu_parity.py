@@ -616,6 +616,29 @@ def test_predictors(golden):
     assert (vi.cpu().numpy() != g["online_grid_vis"]).mean() < 0.01
 
 
+def test_predictor_dense_mode_and_segm_mask(golden):
+    """Dense mode (queries=None, grid_size=0: grid_step^2 chunks, predictor.py:70-98) and the segm_mask grid filter
+    (predictor.py:131-140) against the reference's outputs."""
+    import os
+    from cotracker_amd.predictor import CoTrackerPredictor
+    from cotracker_amd.weights import fill_synthetic_
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "predictor_modes.npz")):
+        pytest.skip("predictor_modes.npz not generated")
+    g = golden("predictor_modes")
+    p = CoTrackerPredictor(checkpoint=None, offline=False, window_len=8)
+    fill_synthetic_(p.model, seed=5)
+    p = p.to(dev())
+    video = t(g["dense_video"])
+    tr, vi = p(video)
+    assert tr.shape == g["dense_tracks"].shape
+    assert maxdiff(tr, g["dense_tracks"]) < 1e-3
+    assert (vi.cpu().numpy() != g["dense_vis"]).mean() < 1e-3
+    tr, vi = p(video, grid_size=12, segm_mask=t(g["segm_mask"]))
+    assert tr.shape == g["segm_tracks"].shape
+    assert maxdiff(tr, g["segm_tracks"]) < 1e-3
+    assert (vi.cpu().numpy() != g["segm_vis"]).mean() < 1e-2
+
+
 def test_full_size_properties():
     """Size-independent properties at C3's window shape (S=16, N=6400): determinism, independence of
     the point-chunking of the correlation stage, and zero update for masked-off support."""

@@ -55,3 +55,63 @@ def test_track_sharded_gloo_world2():
             out = mgr.dict()
             mp.spawn(_worker, args=(2, port, n, out), nprocs=2, join=True)
             assert out[0] and out[1]
+
+
+# ---- the same path on the GPU: two gloo ranks sharing cuda:0, a real tracker under track_sharded -----------------
+import pytest  # noqa: E402
+
+
+def _gpu_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cotracker_amd.predictor import CoTrackerPredictor
+        from cotracker_amd.sharding import track_sharded, chunk_bounds
+        from cotracker_amd.synthetic import synthetic_video
+        from cotracker_amd.weights import fill_synthetic_
+        dev = torch.device("cuda:0")
+        p = CoTrackerPredictor(checkpoint=None, offline=False, window_len=8)
+        fill_synthetic_(p.model, seed=0)
+        p = p.to(dev)
+        video = synthetic_video(12, 96, 160, seed=3).to(dev)
+        g = torch.Generator().manual_seed(1)
+        n = 37  # uneven: 19 + 18
+        q = torch.cat([torch.randint(0, 6, (1, n, 1), generator=g).float(), torch.rand(1, n, 1, generator=g) * 159,
+                       torch.rand(1, n, 1, generator=g) * 95], dim=2).to(dev)
+        tr, vi = track_sharded(p, video, q)
+        # the oracle of SURVEY 8e: the same predictor on the same chunks, one after the other
+        seq_t, seq_v = [], []
+        for r in range(world):
+            lo, hi = chunk_bounds(n, world, r)
+            t_, v_ = p(video, queries=q[:, lo:hi])
+            seq_t.append(t_)
+            seq_v.append(v_)
+        seq_t, seq_v = torch.cat(seq_t, dim=2), torch.cat(seq_v, dim=2)
+        err = float((tr - seq_t).abs().max())
+        flips = int((vi != seq_v).sum())
+        # dense mode (predictor.py:70-98) with its chunks dealt out over the ranks == the sequential dense run
+        p.dense_group = True
+        dt, dv = p(video[:, :8])
+        p.dense_group = None
+        st, sv = p(video[:, :8])
+        derr = float((dt - st).abs().max())
+        dflips = int((dv != sv).sum())
+        out[rank] = (tuple(tr.shape), err, flips, tuple(dt.shape), derr, dflips)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_track_sharded_two_ranks_on_gpu_equals_sequential_chunks():
+    """Two gloo ranks on cuda:0 (the 1-GPU box's stand-in for two GPUs): sharded tracking == the same predictor run on
+    the same contiguous chunks in sequence (the encoder differs run to run by ~5e-6 on MIOpen, hence 1e-4 px, not 0)."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gpu_worker, args=(2, port, out), nprocs=2, join=True)
+        for r in (0, 1):
+            shape, err, flips, dshape, derr, dflips = out[r]
+            assert shape == (1, 12, 37, 2)
+            assert err < 1e-4 and flips == 0, out[r]
+            assert dshape == (1, 8, 4 * 80 * 48, 2)
+            assert derr < 1e-4 and dflips <= 2, out[r]
