@@ -12,8 +12,13 @@ metric = tracked-point-frames/s = N*T / seconds per step, summed over ranks (wea
 rank tracks its own 6400-point chunk; results are all-gathered inside the timed region).
 
 Prints ONE JSON line (rank 0) with the contract keys plus
-  roofline     -- dominant kernel, algorithmic flops / HIP-event duration vs the fp32-MFMA peak
-  cpu_baseline -- the numpy oracle ("port") timed on this host's cores on a bounded sample
+  roofline     -- dominant kernel (recorder rows are per GEMM shape), algorithmic flops / HIP-event duration vs the
+                  split-half MFMA ceiling; roofline_gemm = all Linear launches call-weighted; roofline_sampler = the
+                  correlation sampler against max(measured HBM bytes / 8 TB/s, flops / MFMA ceiling)
+  cpu_baseline -- oracle/torch_port.py (the reference's ATen CPU kernels in the reference's order, encoder included)
+                  timed on this host's cores on a bounded sample of the same workload
+  parity       -- max-abs error of THIS run's tracks / logits against the unmodified reference's CPU outputs at
+                  BASELINE scale (tests/golden/scale_*.npz), next to the reference's own thread-count noise
   kernels      -- per-kernel launch counts / avg duration / achieved rate from the same HIP events
 """
 import argparse
@@ -40,6 +45,11 @@ WORKLOADS = {
     "c2_offline": (256, 256, 48, 20, True, 60, "256x256 T=48 N=400 cotracker3_offline (BASELINE.json configs[1])"),
     "c4_online": (512, 512, 0, 32, False, 16, "512x512 cotracker3_online streaming, 16-frame chunks advancing 8, N=1024, "
                   "window replayed as ONE hipGraph per chunk (BASELINE.json configs[3])"),
+    # BASELINE.json configs[4]: the 265x265 quasi-dense grid (N=70 225) in 8 contiguous chunks (sharding.chunk_bounds),
+    # one chunk of <= 8 779 points per GPU; rank r tracks chunk r, so 1 GPU times chunk 0 (the per-GPU number) and
+    # 8 GPUs the whole job.  grid = 265 is the JOINT grid; points_per_gpu is reported separately.
+    "c5_shard": (512, 512, 120, 265, False, 16, "512x512 T=120 quasi-dense N=70225 (265x265 grid) in 8 contiguous point chunks of "
+                 "<=8779, one per GPU, cotracker3 online-weights sliding window S=16 (BASELINE.json configs[4])"),
     "tiny": (128, 160, 24, 8, False, 8, "smoke-sized"),
     # CoTracker2 (hub entry point cotracker2: window 8, sliding) on the configs[2] video -- not a BASELINE config, the
     # measured line of SURVEY 8f-3
@@ -69,112 +79,155 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(window_len, overlap_factor, iters=6, n_points=96, reps=2):
-    """Numpy oracle (oracle/, kind="port") on a bounded sample of the same workload: one S=16 window,
-    N=96 points on a 96x128 pyramid, 1 update iteration.  Encoder excluded (update path only)."""
-    import numpy as np
-    from oracle import cotracker_oracle as O
-    from cotracker_amd.model import CoTrackerThreeOnline
-    from cotracker_amd.weights import fill_synthetic_
-
-    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=window_len).eval()
-    fill_synthetic_(m, seed=0)
-    p = {k: v.numpy() for k, v in m.state_dict().items() if not k.startswith("fnet.")}
-    r = np.random.RandomState(0)
-    S, N = window_len, n_points
-    f = r.standard_normal((1, S, 128, 96, 128)).astype(np.float32)
-    pyr = O.build_pyramid(O.normalize_fmaps(f))
-    qc = (r.uniform(0, 1, size=(1, N, 2)) * np.array([127, 95])).astype(np.float32)
-    sup = [O.get_track_feat(pyr[i], np.zeros((1, N), np.int64), (qc / np.float32(2 ** i)).astype(np.float32))
-           for i in range(4)]
-    c = np.broadcast_to(qc.reshape(1, 1, N, 2), (1, S, N, 2)).astype(np.float32)
-    z = np.zeros((1, S, N, 1), np.float32)
-    t0 = time.time()
-    for _ in range(reps):
-        O.forward_window(pyr, c, sup, z, z, p, iters=1)
-    dt = (time.time() - t0) / reps
-    units_per_s = S * N / dt                      # (frame, point, iteration) units per second
-    pf_per_s = units_per_s / (iters * overlap_factor)
+def cpu_baseline(workload):
+    """oracle/torch_port.py (kind "port-torch": the ATen CPU ops the reference calls, in its order, encoder included)
+    in a subprocess with glibc malloc tuned (see torch_port.MALLOC_ENV), on a bounded sample of the workload:
+    same video size / window length / weights, fewer frames and points so that it finishes in ~10-30 s."""
+    import subprocess
+    from oracle.torch_port import MALLOC_ENV
+    H, W, T, G, offline, wl, _ = WORKLOADS[workload]
+    if offline is True:
+        kind, frames, grid = "offline", min(T, 48), 20
+    else:  # sliding windows (c3 / c4 / c5): 3 windows of 16 frames, 400 points
+        kind, frames, grid = "sliding", 32, 20
+    env = dict(os.environ, **MALLOC_ENV)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "oracle.torch_port", "--bench", kind, "--frames", str(frames), "--grid", str(grid),
+           "--size", str(H)]
     try:
-        import threadpoolctl
-        cores = max([i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()] or [1])
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
+        return {"value": None, "unit": "tracked-point-frames/s", "cores": os.cpu_count(), "kind": "port-torch",
+                "sample": f"failed: {type(e).__name__}: {e}"}
+    res = {"value": r["tracked_point_frames_per_s"], "unit": "tracked-point-frames/s", "cores": r["threads"],
+           "kind": "port-torch", "host_logical_cpus": os.cpu_count(), "seconds": r["seconds"],
+           "sample": f"oracle/torch_port.py predictor path incl. encoder, {kind}, {r['video'][0]}x{r['video'][1]} video, "
+                     f"T={r['frames']}, N={r['points']} (grid {grid}), 6 iterations, {r['threads']} threads, glibc malloc "
+                     f"tuned ({r['malloc_tuned']}): {r['seconds']} s; value = N*T/s of that sample (not rescaled)"}
+    # what the UNMODIFIED reference did in the build container on the BASELINE-scale goldens (recorded by
+    # tests/golden/make_golden_scale.py): same metric, different host
+    try:
+        import numpy as np
+        ref = {}
+        for name in ("c2", "c4", "c3_g40", "c3_g80"):
+            f = os.path.join(ROOT, "tests", "golden", f"scale_{name}.npz")
+            if os.path.exists(f):
+                g = np.load(f)
+                n, t = g["coords"].shape[1], g["coords"].shape[0]
+                ref[name] = {"tracked_point_frames_per_s": round(n * t / float(g["seconds"]), 1), "threads": int(g["threads"]),
+                             "host_cpus": int(g["host_cpus"]), "seconds": round(float(g["seconds"]), 1)}
+        res["reference_in_build_container"] = ref
     except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": round(pf_per_s, 2), "unit": "tracked-point-frames/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy oracle, update path only (no encoder): 1 window S={S}, N={N}, 1 iteration "
-                      f"({dt:.1f} s) on a 96x128 4-level pyramid; scaled by {iters} iters x {overlap_factor:.3f} window overlap",
-            "host_logical_cpus": os.cpu_count()}
+        pass
+    return res
 
 
-def roofline_entry(row, traffic, force_hbm=False):
-    """Roofline object of one kernel row of the HIP-event recorder.  `achieved` = ALGORITHMIC work of the launches /
-    their summed HIP-event duration.  Split-half kernels (gemm_sh_* / gemm_f16x3_* / corr_volume_sh) form every
-    f32-class product from 3 f16 MFMAs, so their MFMA ceiling in algorithmic flops is 2500/3 = 833 TF/s."""
-    name = row["name"]
-    sec = row["total_ms"] * 1e-3
-    n = max(row["launches"], 1)
-    tr = traffic.get(name)
-    out = {"kernel": name, "launches": row["launches"], "avg_launch_us": round(1e6 * sec / n, 1)}
-    if force_hbm:
-        gbs = row["bytes"] / sec / 1e9
-        out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": row["bytes"] / n,
-                    "note": "algorithmic sampler bytes (SURVEY 8d: 8x8x128 footprint per (t,n,level) + support/S + volume out, "
-                            "no inter-point reuse assumed) / HIP-event time; neighbouring grid points share footprint pixels "
-                            "in L2, so measured HBM traffic is lower than the algorithmic figure"})
-    else:
-        ach = row["flops"] / sec / 1e12
-        split = name.startswith(("gemm_sh", "gemm_f16x3", "corr_volume_sh"))
-        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
-        out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "flops_per_launch": row["flops"] / n})
-        if split:
-            out.update({"mfma_issued": round(3 * ach, 1), "mfma_peak": F16_MFMA_PEAK_TFLOPS, "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
-                        "note": "achieved = algorithmic (f32-equivalent) flops / HIP-event time; every product is 3 "
-                                "v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, f32 accumulate), so peak = dense f16 MFMA "
-                                "2500 TF/s / 3; frac is also mfma_issued / mfma_peak.  The exact-f32 MFMA peak is 157.3 TF/s"})
-        else:
-            out["note"] = "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) peak"
+def _traffic_fields(out, tr):
     if tr:
         out["traffic"] = tr.get("hbm_bytes_per_launch")
         out["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "dispatches", "source") if k in tr}
+        out["traffic_note"] = ("HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload "
+                               "(tools/pmc_traffic.py -> profiles/pmc_traffic.json, a committed file; not re-measured in this run)")
     else:
         out["traffic"] = None
     return out
 
 
-def parity_probe(dev):
-    """Tiny window vs the oracle (same check as __graft_entry__.smoke): max-abs errors."""
-    import numpy as np
-    from oracle import cotracker_oracle as O
-    from cotracker_amd import ops
-    from cotracker_amd.model import CoTrackerThreeOnline
-    from cotracker_amd.weights import fill_synthetic_
+SPLIT_NOTE = ("achieved = algorithmic (f32-equivalent) flops / HIP-event time; every product is 3 v_mfma_f32_32x32x16_f16 "
+              "(hi*hi + hi*lo + lo*hi, f32 accumulate), so peak = dense f16 MFMA 2500 TF/s / 3; frac is also mfma_issued / "
+              "mfma_peak.  The exact-f32 MFMA peak is 157.3 TF/s")
 
-    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(96, 128)).eval()
-    fill_synthetic_(m, seed=3)
-    p = {k: v.numpy() for k, v in m.state_dict().items() if not k.startswith("fnet.")}
-    m = m.to(dev)
-    r = np.random.RandomState(0)
-    S, N = 8, 12
-    f = r.standard_normal((1, S, 128, 24, 32)).astype(np.float32)
-    pyr = O.build_pyramid(O.normalize_fmaps(f))
-    qf = r.randint(0, S, size=(1, N))
-    qc = (r.uniform(0, 1, size=(1, N, 2)) * np.array([31, 23])).astype(np.float32)
-    sup = [O.get_track_feat(pyr[i], qf, (qc / np.float32(2 ** i)).astype(np.float32)) for i in range(4)]
-    cinit = np.broadcast_to(qc.reshape(1, 1, N, 2), (1, S, N, 2)).astype(np.float32)
-    z = np.zeros((1, S, N, 1), np.float32)
-    c, v, cf = O.forward_window(pyr, cinit, sup, z, z, p, iters=6, model_resolution=(96, 128))
-    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    fm = [T(np.transpose(x[0], (0, 2, 3, 1))) for x in pyr]
-    sp = [T(np.transpose(s[0], (1, 0, 2))) for s in sup]
-    coords, vis, conf = T(cinit[0]), torch.zeros(S, N, device=dev), torch.zeros(S, N, device=dev)
-    ops.forward_window(ops.Window(fm, sp, coords, vis, conf, (32.0, 24.0), iters=6), m.packed(dev))
-    torch.cuda.synchronize()
-    return {"coords_px": float((coords.cpu() - torch.from_numpy(c[0])).abs().max()) * 4.0,
-            "vis_logit": float((vis.cpu() - torch.from_numpy(v[0, ..., 0])).abs().max()),
-            "conf_logit": float((conf.cpu() - torch.from_numpy(cf[0, ..., 0])).abs().max()),
-            "against": "numpy oracle, S=8 N=12 6 iterations"}
+
+def roofline_mfma(name, rows, traffic):
+    """MFMA roofline of one recorder row, or of several rows together (call-weighted: summed flops / summed time).
+    Split-half kernels form every f32-class product from 3 f16 MFMAs -> ceiling 2500/3 = 833 TF/s algorithmic."""
+    sec = sum(r["total_ms"] for r in rows) * 1e-3
+    n = max(sum(r["launches"] for r in rows), 1)
+    flops = sum(r["flops"] for r in rows)
+    ach = flops / sec / 1e12
+    split = name.startswith(("gemm_sh", "gemm_f16x3", "corr_volume_sh", "corr_fused", "gemm (all"))
+    peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
+    out = {"kernel": name, "launches": n, "avg_launch_us": round(1e6 * sec / n, 1), "bound": "mfma", "achieved": round(ach, 2),
+           "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flops_per_launch": flops / n}
+    if split:
+        out.update({"mfma_issued": round(3 * ach, 1), "mfma_peak": F16_MFMA_PEAK_TFLOPS, "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
+                    "note": SPLIT_NOTE})
+    else:
+        out["note"] = "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) peak"
+    return _traffic_fields(out, traffic.get(name) if len(rows) == 1 else None)
+
+
+def roofline_sampler(row, traffic):
+    """The correlation sampler against ITS roofline: the larger of (measured HBM bytes / 8 TB/s) and (contraction flops /
+    split-half MFMA ceiling).  frac = that bound / the measured launch time.  SURVEY 8d's no-reuse algorithmic bytes
+    (every point re-reads its own 8x8x128 footprint) are kept as a secondary field: neighbouring grid points share
+    footprint pixels in L2 / Infinity Cache, so that figure is NOT what reaches HBM."""
+    name = row["name"]
+    sec = row["total_ms"] * 1e-3
+    n = max(row["launches"], 1)
+    t_launch = sec / n
+    tr = traffic.get(name)
+    peak_tf = F16_MFMA_PEAK_TFLOPS / 3.0
+    t_mfma = row["flops"] / n / (peak_tf * 1e12)
+    out = {"kernel": name, "launches": row["launches"], "avg_launch_us": round(1e6 * t_launch, 1),
+           "flops_per_launch": row["flops"] / n, "mfma_TFLOPs": round(row["flops"] / sec / 1e12, 2),
+           "mfma_frac": round(row["flops"] / sec / 1e12 / peak_tf, 4),
+           "algorithmic_bytes_per_launch_no_reuse": row["bytes"] / n,
+           "algorithmic_GBs_no_reuse": round(row["bytes"] / sec / 1e9, 1)}
+    if tr and tr.get("hbm_bytes_per_launch"):
+        hbm = tr["hbm_bytes_per_launch"]
+        t_hbm = hbm / (HBM_PEAK_GBS * 1e9)
+        bound = "hbm" if t_hbm >= t_mfma else "mfma"
+        t_bound = max(t_hbm, t_mfma)
+        out.update({"bound": bound, "achieved": round(hbm / t_launch / 1e9, 1) if bound == "hbm" else out["mfma_TFLOPs"],
+                    "peak": HBM_PEAK_GBS if bound == "hbm" else round(peak_tf, 1), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                    "frac": round(t_bound / t_launch, 4), "hbm_GBs_measured": round(hbm / t_launch / 1e9, 1),
+                    "hbm_frac": round(hbm / t_launch / 1e9 / HBM_PEAK_GBS, 4), "roofline_bound_us": round(1e6 * t_bound, 1),
+                    "note": "frac = max(measured HBM bytes / 8 TB/s, flops / 833 TF/s) / measured launch time"})
+    else:  # no PMC pass for this kernel on this workload: only the MFMA side is known
+        out.update({"bound": "mfma", "achieved": out["mfma_TFLOPs"], "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                    "frac": out["mfma_frac"], "note": "no PMC traffic for this kernel/workload: MFMA side only; HBM traffic unmeasured"})
+    return _traffic_fields(out, tr)
+
+
+def golden_parity(name, coords, vis_logit, conf_logit, coords_key="coords"):
+    """Max-abs error against the unmodified reference's CPU run (tests/golden/scale_<name>.npz): coords_key "coords" =
+    model.forward()[0] in model-resolution px, "tracks" = the predictor's output in raw-video px (after the query-frame
+    overwrite); logits are the pre-sigmoid visibility / confidence."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", f"scale_{name}.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    err = lambda a, b: float(np.abs(a.detach().double().cpu().numpy() - b.astype(np.float64)).max())  # noqa: E731
+    return {"against": f"unmodified reference, CPU fp32, {str(g['meta'])} (tests/golden/scale_{name}.npz)",
+            "coords_px": err(coords, g[coords_key]), "vis_logit": err(vis_logit, g["vis_logit"]),
+            "conf_logit": err(conf_logit, g["conf_logit"]),
+            "reference_own_noise": {"threads": [int(g["threads"]), int(g["noise_threads"])],
+                                    "coords_px": float(g["noise_coords_max"]), "vis_logit": float(g["noise_vis_logit_max"]),
+                                    "conf_logit": float(g["noise_conf_logit_max"])}}
+
+
+def c2_parity(dev, precision):
+    """BASELINE configs[1] end to end (predictor, encoder included) against the reference golden: 68 ms on the GPU."""
+    from cotracker_amd import model as M
+    from cotracker_amd.predictor import CoTrackerPredictor
+    from cotracker_amd.synthetic import synthetic_video
+    from cotracker_amd.weights import fill_synthetic_
+    old, M.DEFAULT_PRECISION = M.DEFAULT_PRECISION, precision
+    try:
+        p = CoTrackerPredictor(checkpoint=None, offline=True, window_len=60)
+    finally:
+        M.DEFAULT_PRECISION = old
+    fill_synthetic_(p.model, seed=0)
+    p = p.to(dev)
+    cap = {}
+    fwd = p.model.forward
+    p.model.forward = lambda *a, **k: cap.setdefault("out", fwd(*a, **k))
+    p(synthetic_video(48, 256, 256, seed=1234).to(dev), grid_size=20)
+    vl, cl = p.model.last_logits
+    return golden_parity("c2", cap["out"][0][0], vl[0], cl[0])
 
 
 def main():
@@ -199,13 +252,14 @@ def main():
     from cotracker_amd import ops
     from cotracker_amd.predictor import CoTrackerPredictor, get_points_on_a_grid
     ctk_model.DEFAULT_PRECISION = args.precision
-    from cotracker_amd.sharding import all_gather_tracks
+    from cotracker_amd.sharding import all_gather_tracks, chunk_bounds, track_sharded
     from cotracker_amd.synthetic import synthetic_video
     from cotracker_amd.weights import fill_synthetic_
 
     H, W, T, G, offline, wl, desc = WORKLOADS[args.workload]
     N = G * G
     streaming = args.workload == "c4_online"
+    c5 = args.workload == "c5_shard"
     if streaming:
         from cotracker_amd.predictor import CoTrackerOnlinePredictor
         pred = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
@@ -218,6 +272,10 @@ def main():
     fill_synthetic_(pred.model, seed=0)
     pred = pred.to(dev)
     video = synthetic_video(T, H, W, seed=1234).to(dev)  # resident in HBM before timing starts
+    ih, iw = pred.interp_shape
+    to_raw = torch.tensor([(W - 1) / (iw - 1), (H - 1) / (ih - 1)], device=dev)  # model-resolution px -> raw-video px
+    sharding = f"points x{world}"
+    n_per_rank = N
 
     if streaming:
         # CoTrackerOnlinePredictor protocol (predictor.py:228-300): first call registers the grid queries, then every
@@ -231,20 +289,36 @@ def main():
             i = cursor[0]
             cursor[0] += pred.step
             return pred(video_chunk=video[:, i:i + 2 * pred.step])
+    elif c5:
+        # the joint 265x265 grid, split into 8 contiguous chunks in row-major grid order; rank r tracks
+        # chunk r as ONE model call (the virtual tracks couple the points of a call: a chunk is a call, predictor.py:80-96)
+        if world > 8:
+            raise SystemExit("c5_shard defines 8 chunks")
+        pts = get_points_on_a_grid(G, (ih, iw), device=dev) * to_raw
+        q_all = torch.cat([torch.zeros_like(pts[:, :, :1]), pts], dim=2)
+        lo, hi = chunk_bounds(N, 8, rank)
+        q = q_all[:, lo:hi].contiguous()
+        n_per_rank = hi - lo
+        sharding = f"chunk {rank} of 8 per rank ({world} of 8 chunks tracked: {'the whole job' if world == 8 else 'per-GPU rate of the 8-GPU job'})"
+        n_gather = sum(chunk_bounds(N, 8, r)[1] - chunk_bounds(N, 8, r)[0] for r in range(world))
+
+        def step():
+            tr, vi = pred(video, queries=q)
+            return all_gather_tracks(tr, vi, n_gather) if world > 1 else (tr, vi)
     elif world == 1:
         def step():
             return pred(video, grid_size=G)
     else:
-        # weak scaling: rank r tracks its own G*G grid, shifted by a sub-pixel offset (a denser joint grid)
-        ih, iw = pred.interp_shape
-        pts = get_points_on_a_grid(G, (ih, iw), device=dev)
-        pts = pts + torch.tensor([0.37, 0.23], device=dev) * rank
-        pts = pts * torch.tensor([(W - 1) / (iw - 1), (H - 1) / (ih - 1)], device=dev)  # raw-video pixels
-        q = torch.cat([torch.zeros_like(pts[:, :, :1]), pts], dim=2)
+        # weak scaling of the BASELINE configs[2] job: the query list is `world` G x G grids (each shifted by a sub-pixel
+        # offset: a denser joint grid of world*N points), split into contiguous chunks by sharding.chunk_bounds; every
+        # rank tracks its chunk as one call and ONE all-gather (RCCL) returns the full tracks to every rank.
+        base = get_points_on_a_grid(G, (ih, iw), device=dev)
+        pts = torch.cat([base + torch.tensor([0.37, 0.23], device=dev) * r for r in range(world)], dim=1) * to_raw
+        q_all = torch.cat([torch.zeros_like(pts[:, :, :1]), pts], dim=2)
+        sharding = f"{world * N} queries in {world} contiguous chunks of {N} (sharding.track_sharded), one all-gather"
 
         def step():
-            tr, vi = pred(video, queries=q)
-            return all_gather_tracks(tr, vi, N * world)  # final tracks of every rank on every rank (RCCL)
+            return track_sharded(pred, video, q_all)
 
     def sync():
         torch.cuda.synchronize()
@@ -265,8 +339,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     sec_per_step = float(tmax.item()) / args.steps
     assert torch.isfinite(out[0]).all()
+    assert pred.model.range_fallbacks == 0 if hasattr(pred.model, "range_fallbacks") else True
     frames_per_step = pred.step if streaming else T
-    value = world * N * frames_per_step / sec_per_step
+    if c5:
+        total_points = sum(chunk_bounds(N, 8, r)[1] - chunk_bounds(N, 8, r)[0] for r in range(world))
+    else:
+        total_points = world * N
+    value = total_points * frames_per_step / sec_per_step
 
     result = {
         "metric": "tracked-point-frames/sec (N*T/s)", "value": round(value, 1), "unit": "tracked-point-frames/s",
@@ -274,13 +353,31 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (Linear layers as split-half f16 MFMA x3, f32 accumulate)" if args.precision == "f16x3" else "f32",
         "data": "synthetic",
-        "config": {"workload": desc, "name": args.workload, "points_per_gpu": N, "frames": frames_per_step, "video": [H, W],
-                   "iters": 6, "window_len": wl, "offline": bool(offline) and offline != "v2", "sharding": f"points x{world}", "precision": args.precision,
-                   "weights": "seeded synthetic (no checkpoints offline)"},
+        "config": {"workload": desc, "name": args.workload, "points_per_gpu": n_per_rank, "frames": frames_per_step, "video": [H, W],
+                   "iters": 6, "window_len": wl, "offline": bool(offline) and offline != "v2", "sharding": sharding,
+                   "precision": args.precision, "weights": "seeded synthetic (no checkpoints offline)"},
     }
     if streaming:
         result["config"]["hip_graph"] = bool(pred.model.hip_graph)
         result["config"]["graph_nodes"] = next(iter(pred.model._graphs.values())).nodes if pred.model._graphs else 0
+
+    # parity of what was just timed: the last timed step's model-level outputs against the reference's CPU run of the
+    # same workload (world == 1, c3_sliding / c2_offline have goldens at exactly these sizes), plus C2 end to end
+    if rank == 0:
+        parity = {}
+        golden_name = {"c3_sliding": "c3_g80", "c2_offline": "c2"}.get(args.workload)
+        if world == 1 and golden_name and getattr(pred.model, "last_logits", None) is not None:
+            vl, cl = pred.model.last_logits
+            gp = golden_parity(golden_name, out[0][0], vl[0], cl[0], coords_key="tracks")
+            if gp:
+                gp["note"] = "outputs of the LAST TIMED step: predictor tracks (raw-video px) and the model's pre-sigmoid logits"
+                parity["timed_step"] = gp
+        if args.workload != "c2_offline":
+            try:
+                parity["c2"] = c2_parity(dev, args.precision)
+            except Exception as e:
+                parity["c2"] = {"error": f"{type(e).__name__}: {e}"}
+        result["parity"] = parity
 
     if rank == 0 and not args.no_profile:
         # one extra step with the library's HIP-event recorder on (events on the launch stream)
@@ -288,7 +385,7 @@ def main():
             pred.model.hip_graph = False  # events cannot be recorded inside a captured graph: profile the direct launches
         ops.profile_enable(True)
         t1 = time.perf_counter()
-        step() if streaming else pred(video, grid_size=G)
+        step()
         torch.cuda.synchronize()
         prof_step_s = time.perf_counter() - t1
         rows = ops.profile_read()
@@ -304,25 +401,31 @@ def main():
         result["kernels"] = kern
         result["profiled_step_ms"] = round(prof_step_s * 1e3, 1)
         result["hip_kernels_ms"] = round(sum(r["total_ms"] for r in rows), 1)
+        result["profile_note"] = ("kernels / roofline come from ONE extra step run after the timed ones with a HIP-event pair around "
+                                  "every launch (events serialise the stream and add ~5 us per launch, so hip_kernels_ms + encoder "
+                                  "can exceed ms_per_step); rocprofv3 --kernel-trace --stats of the same command is in profiles/")
         traffic = {}
         if os.path.exists(args.pmc_traffic):
             traffic = json.load(open(args.pmc_traffic))
             if traffic.pop("_workload", "c3_sliding") != args.workload:
                 traffic = {}  # the PMC passes were collected on another workload: per-launch bytes do not transfer
+        gemm_rows = [r for r in rows if r["name"].startswith(("gemm_sh", "gemm_f16x3", "gemm_f32", "mlp_sh"))]
         if rows:
-            result["roofline"] = roofline_entry(rows[0], traffic)
-            for r in rows:
-                if r["name"].startswith("corr_volume"):
-                    result["roofline_sampler"] = roofline_entry(r, traffic, force_hbm=True)
-    if rank == 0:
-        result["parity"] = parity_probe(dev)
+            dom = rows[0]
+            result["roofline"] = roofline_sampler(dom, traffic) if dom["name"].startswith("corr_") else roofline_mfma(dom["name"], [dom], traffic)
+        if gemm_rows:
+            result["roofline_gemm"] = roofline_mfma("gemm (all Linear launches, call-weighted)", gemm_rows, traffic)
+            result["roofline_gemm"]["rows"] = [{"name": r["name"], "launches": r["launches"],
+                                                "avg_us": round(1e3 * r["total_ms"] / max(r["launches"], 1), 1),
+                                                "frac": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12 /
+                                                              (F16_MFMA_PEAK_TFLOPS / 3.0 if not r["name"].startswith("gemm_f32") else FP32_MFMA_PEAK_TFLOPS), 4)}
+                                               for r in gemm_rows if r["total_ms"] > 0]
+        for r in rows:
+            if r["name"].startswith("corr_"):
+                result["roofline_sampler"] = roofline_sampler(r, traffic)
+                break
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        overlap = 1.0
-        if not offline or offline == "v2":
-            S, step_ = wl, wl // 2
-            nwin = (T - S + step_ - 1) // step_ + 1
-            overlap = nwin * S / T
-        result["cpu_baseline"] = cpu_baseline(16 if not offline else 16, overlap)  # CoTracker3 update path sample
+        result["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -19,7 +19,7 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -88,6 +88,27 @@ class FormerWeights(C.Structure):
     ]
 
 
+class V2WindowArgs(C.Structure):
+    """ctk_v2_window_args: one CoTracker2 window (cotracker.py:86-173)."""
+    _fields_ = [
+        ("S", C.c_int32), ("N", C.c_int32), ("iters", C.c_int32),
+        ("H", C.c_int32 * LEVELS), ("W", C.c_int32 * LEVELS),
+        ("fmaps", _fp * LEVELS),
+        ("coords", _fp), ("track_feat", _fp), ("vis", _fp), ("track_mask", _fp), ("point_mask", _fp), ("vis_out", _fp),
+    ]
+
+
+class V2Weights(C.Structure):
+    """ctk_v2_weights."""
+    _fields_ = [
+        ("former", FormerWeights),
+        ("pos_hwc", _fp), ("pos_h", C.c_int32), ("pos_w", C.c_int32),
+        ("norm_w", _fp), ("norm_b", _fp),
+        ("upd_w", _fp), ("upd_p", _fp), ("upd_b", _fp),
+        ("vis_w", _fp), ("vis_b", _fp),
+    ]
+
+
 class ProfileRow(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -113,6 +134,9 @@ SYMBOLS = {
     "ctk_update_former_workspace_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
     "ctk_update_former": (C.c_int, [C.c_int32, C.c_int32, _fp, _P(ModelWeights), _fp, _fp, C.c_size_t, _fp]),
     "ctk_update_former_ex": (C.c_int, [C.c_int32, C.c_int32, _fp, C.c_int32, _P(FormerWeights), _fp, _fp, _fp, C.c_size_t, _fp]),
+    "ctk_forward_window_v2_workspace_bytes": (C.c_int, [_P(V2WindowArgs), _P(V2Weights), _P(C.c_size_t)]),
+    "ctk_forward_window_v2": (C.c_int, [_P(V2WindowArgs), _P(V2Weights), _fp, C.c_size_t, _fp]),
+    "ctk_v2_window_graph_create": (C.c_int, [_P(V2WindowArgs), _P(V2Weights), _fp, C.c_size_t, _P(C.c_void_p)]),
     "ctk_v2_assemble": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int32, _fp, C.c_int32, _fp]),
     "ctk_v2_apply_delta": (C.c_int, [C.c_int32, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, C.c_float, _fp, _fp]),
     "ctk_v2_vis_head": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp]),

@@ -446,19 +446,10 @@ struct ctk_window_graph {
   int64_t nodes;
 };
 
-extern "C" int ctk_window_graph_create(const ctk_window_args* a, const ctk_model_weights* w, void* workspace,
-                                       size_t workspace_bytes, ctk_window_graph** out) {
-  if (!out) return CTK_E_NULL;
-  *out = nullptr;
-  if (ctk_profile_is_on()) return CTK_E_STATE;
-  // validate before touching the capture machinery (ctk_forward_window repeats these checks)
-  CTK_TRY(check_window(a));
-  CTK_TRY(check_weights(w));
-  if (!workspace || !a->coords || !a->vis || !a->conf) return CTK_E_NULL;
-  size_t need = 0;
-  CTK_TRY(ctk_forward_window_workspace_bytes(a, &need));
-  if (need > workspace_bytes) return CTK_E_WORKSPACE;
-
+namespace {
+// Capture `enqueue(stream)` on a private stream into an instantiated graph.
+template <typename F>
+int capture_graph(F enqueue, ctk_window_graph** out) {
   hipStream_t cs = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
   if (e != hipSuccess) return (int)e;
@@ -468,7 +459,7 @@ extern "C" int ctk_window_graph_create(const ctk_window_args* a, const ctk_model
     (void)hipStreamDestroy(cs);
     return (int)e;
   }
-  const int rc = ctk_forward_window(a, w, workspace, workspace_bytes, cs);
+  const int rc = enqueue(cs);
   hipGraph_t graph = nullptr;
   e = hipStreamEndCapture(cs, &graph);
   (void)hipStreamDestroy(cs);
@@ -492,6 +483,117 @@ extern "C" int ctk_window_graph_create(const ctk_window_args* a, const ctk_model
   }
   *out = g;
   return CTK_OK;
+}
+}  // namespace
+
+extern "C" int ctk_window_graph_create(const ctk_window_args* a, const ctk_model_weights* w, void* workspace,
+                                       size_t workspace_bytes, ctk_window_graph** out) {
+  if (!out) return CTK_E_NULL;
+  *out = nullptr;
+  if (ctk_profile_is_on()) return CTK_E_STATE;
+  // validate before touching the capture machinery (ctk_forward_window repeats these checks)
+  CTK_TRY(check_window(a));
+  CTK_TRY(check_weights(w));
+  if (!workspace || !a->coords || !a->vis || !a->conf) return CTK_E_NULL;
+  size_t need = 0;
+  CTK_TRY(ctk_forward_window_workspace_bytes(a, &need));
+  if (need > workspace_bytes) return CTK_E_WORKSPACE;
+  return capture_graph([&](hipStream_t cs) { return ctk_forward_window(a, w, workspace, workspace_bytes, cs); }, out);
+}
+
+// ---- CoTracker2 window driver (cotracker.py:86-173): one capture-safe call per window --------------------------
+namespace {
+struct V2Ws {
+  float* pos;     // [N,456]
+  float* fcorrs;  // [N,S,196]
+  float* x;       // [N*S,in_ld]  (f32 or SH: same bytes)
+  float* delta;   // [N*S,out_ld]
+  float* normed;  // [S*N,128]
+  void* former;   // update-former workspace
+  size_t former_bytes;
+  size_t bytes;
+};
+
+V2Ws carve_v2(const ctk_v2_window_args* a, const ctk_v2_weights* w, void* base) {
+  V2Ws r;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* q = reinterpret_cast<float*>(p + off);
+    off += align256(nfloat * sizeof(float));
+    return q;
+  };
+  const size_t rows = (size_t)a->N * a->S;
+  r.pos = take((size_t)a->N * w->former.in_dim);
+  r.fcorrs = take(rows * CTK_LEVELS * CTK_TAPS);
+  r.x = take(rows * w->former.in_ld);
+  r.delta = take(rows * w->former.out_ld);
+  r.normed = take(rows * CTK_C);
+  r.former = p + off;
+  r.former_bytes = carve_uf(a->S, a->N, nullptr).bytes;
+  off += r.former_bytes;
+  r.bytes = off;
+  return r;
+}
+
+int check_v2(const ctk_v2_window_args* a, const ctk_v2_weights* w) {
+  if (!a || !w) return CTK_E_NULL;
+  if (a->S <= 0 || a->N <= 0 || a->iters < 0) return CTK_E_SHAPE;
+  if (w->former.in_dim != 456 || w->former.out_dim != CTK_C + 2 || w->former.in_ld < 456 || (w->former.in_ld % 32) ||
+      w->former.out_ld < CTK_C + 2 || (w->former.out_ld % 64))
+    return CTK_E_SHAPE;
+  if (!a->coords || !a->track_feat || !a->vis || !a->track_mask || !a->vis_out) return CTK_E_NULL;
+  if (!w->pos_hwc || !w->norm_w || !w->norm_b || (!w->upd_w && !w->upd_p) || !w->upd_b || !w->vis_w || !w->vis_b) return CTK_E_NULL;
+  if (w->pos_h <= 0 || w->pos_w <= 0) return CTK_E_SHAPE;
+  for (int l = 0; l < CTK_LEVELS; ++l) {
+    if (!a->fmaps[l]) return CTK_E_NULL;
+    if (a->H[l] <= 0 || a->W[l] <= 0) return CTK_E_SHAPE;
+  }
+  return CTK_OK;
+}
+}  // namespace
+
+extern "C" int ctk_forward_window_v2_workspace_bytes(const ctk_v2_window_args* a, const ctk_v2_weights* w, size_t* out_bytes) {
+  if (!out_bytes) return CTK_E_NULL;
+  CTK_TRY(check_v2(a, w));
+  *out_bytes = carve_v2(a, w, nullptr).bytes;
+  return CTK_OK;
+}
+
+extern "C" int ctk_forward_window_v2(const ctk_v2_window_args* a, const ctk_v2_weights* w, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  CTK_TRY(check_v2(a, w));
+  if (!workspace) return CTK_E_NULL;
+  if (!ctk_aligned16(workspace)) return CTK_E_ALIGN;
+  const V2Ws ws = carve_v2(a, w, workspace);
+  if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
+  const ctk_former_weights* fw = &w->former;
+  const int x_split = fw->in_p != nullptr;
+  const int S = a->S, N = a->N;
+  // sampled_pos_emb: pos_emb at the FIRST frame's coordinates of the window (cotracker.py:126-130), fixed over the iterations
+  CTK_TRY(ctk_sample_features4d(w->pos_hwc, w->pos_h, w->pos_w, fw->in_dim, a->coords, N, ws.pos, stream));
+  for (int it = 0; it < a->iters; ++it) {                                                             // cotracker.py:132
+    CTK_TRY(ctk_corrblock_sample(a->fmaps, a->H, a->W, S, N, a->track_feat, a->coords, ws.fcorrs, stream));   // :134-137
+    CTK_TRY(ctk_v2_assemble(S, N, a->coords, ws.fcorrs, a->track_feat, a->track_mask, a->vis, ws.pos, fw->in_ld, ws.x, x_split,
+                            stream));                                                                  // :139-150
+    CTK_TRY(ctk_update_former_ex(S, N, ws.x, x_split, fw, a->point_mask, ws.delta, ws.former, ws.former_bytes, stream));  // :152-155
+    CTK_TRY(ctk_v2_apply_delta(S, N, ws.delta, fw->out_ld, a->coords, w->norm_w, w->norm_b, 1e-5f, ws.normed, stream));  // :157-159,167
+    // track_feat += GELU(Linear(GroupNorm(delta_feats)))   (track_feat_updater, cotracker.py:162-170), rows t*N+n
+    CTK_TRY(gemm(ws.normed, CTK_C, S * N, WRef{w->upd_w, w->upd_p}, CTK_C, CTK_C, CTK_C, a->track_feat, CTK_C, w->upd_b, CTK_ACT_GELU_ERF,
+                 a->track_feat, CTK_C, static_cast<hipStream_t>(stream)));
+  }
+  return ctk_v2_vis_head(a->track_feat, (int64_t)S * N, w->vis_w, w->vis_b, a->vis_out, stream);   // :172
+}
+
+extern "C" int ctk_v2_window_graph_create(const ctk_v2_window_args* a, const ctk_v2_weights* w, void* workspace,
+                                          size_t workspace_bytes, ctk_window_graph** out) {
+  if (!out) return CTK_E_NULL;
+  *out = nullptr;
+  if (ctk_profile_is_on()) return CTK_E_STATE;
+  CTK_TRY(check_v2(a, w));
+  if (!workspace) return CTK_E_NULL;
+  if (carve_v2(a, w, nullptr).bytes > workspace_bytes) return CTK_E_WORKSPACE;
+  return capture_graph([&](hipStream_t cs) { return ctk_forward_window_v2(a, w, workspace, workspace_bytes, cs); }, out);
 }
 
 extern "C" int ctk_window_graph_launch(ctk_window_graph* g, void* stream) {

@@ -23,6 +23,7 @@
 #include "ctk_common.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -511,6 +512,13 @@ int launch_with_lds(K kernel, unsigned blocks, unsigned threads, size_t lds_byte
 }  // namespace
 
 int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
+  // recorder rows are per (tile, K, N): the K = 384 Linears and corr_mlp.fc1 (K = 2432) sit at very different
+  // fractions of the MFMA ceiling and must not be averaged under one name
+  char pname[32];
+  auto prof_name = [&](const char* tile) {
+    snprintf(pname, sizeof(pname), "gemm_sh_%s_k%d_n%d", tile, g.K, g.N);
+    return pname;
+  };
 
   const long blocks128 = (long)((g.M + 127) / 128) * (g.N / 128) * g.batch;
   const bool big = (g.N % 128) == 0 && blocks128 >= 384;
@@ -532,7 +540,7 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
       // Default for the N % 256 == 0 Linears that have a compile-time epilogue (to_kv, mlp.fc1, corr_mlp.fc2):
       // -5..-11 % per launch in tools/bench_gemm.py, -0.6 % per C3 step measured in situ.  CTK_GEMM_TILE=1 disables.
       g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 256;
-      CtkProfScope ps("gemm_sh_256x256", flops, bytes, s);
+      CtkProfScope ps(prof_name("256"), flops, bytes, s);
       const dim3 grid((unsigned)((long)g.mblocks * g.nblocks * g.batch)), blk(512);
       if (code256 == epi_code(CTK_ACT_NONE, false, false, false, true))
         hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 4, 2, 2, epi_code(CTK_ACT_NONE, false, false, false, true)>), grid, blk, 0, s, g);
@@ -566,7 +574,7 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
       // CTK_GEMM_TILE=5: 64x128 tile (wave 32x64, 48 KB of LDS -> three workgroups per CU instead of two)
       const bool t64 = pref == 5;
       if (t64) { g.mblocks = (g.M + 63) / 64; }
-      CtkProfScope ps(t64 ? "gemm_sh_64x128" : "gemm_sh_128x128", flops, bytes, s);
+      CtkProfScope ps(prof_name(t64 ? "64x128" : "128"), flops, bytes, s);
       const dim3 grid((unsigned)((long)g.mblocks * g.nblocks * g.batch)), blk(256);
 #define CTK_SH128(E)                                                                     \
   do {                                                                                   \
@@ -587,7 +595,7 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
 #undef CTK_SH128
     } else {
       g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
-      CtkProfScope ps("gemm_sh_64x64", flops, bytes, s);
+      CtkProfScope ps(prof_name("64"), flops, bytes, s);
       hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
     }
   } else if (big) {

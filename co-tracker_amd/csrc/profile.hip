@@ -12,7 +12,7 @@
 namespace {
 struct Rec {
   hipEvent_t a, b;
-  const char* name;
+  char name[32];  // copied: launchers build per-shape names on the stack
   double flops, bytes;
 };
 std::vector<Rec> g_recs;
@@ -38,7 +38,8 @@ CtkProfScope::CtkProfScope(const char* name, double flops, double bytes, hipStre
   Rec r;
   r.a = get_event();
   r.b = get_event();
-  r.name = name;
+  std::strncpy(r.name, name, sizeof(r.name) - 1);
+  r.name[sizeof(r.name) - 1] = 0;
   r.flops = flops;
   r.bytes = bytes;
   (void)hipEventRecord(r.a, s);

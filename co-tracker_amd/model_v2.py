@@ -57,6 +57,8 @@ class CoTracker2(nn.Module):
         self.track_feat_updater = nn.Sequential(_Lin(self.latent_dim, self.latent_dim))  # + nn.GELU() (no parameters)
         self.vis_predictor = nn.Sequential(_Lin(self.latent_dim, 1))
         self._packed = None
+        self.hip_graph = False   # streaming (is_online=True): replay the captured window graph; not a reference kwarg
+        self._graphs = {}
         from . import model as _m
         self.precision = _m.DEFAULT_PRECISION  # Linear back end: "f16x3" (split-half MFMA) | "f32"; not a reference kwarg
 
@@ -137,24 +139,50 @@ class PackedWeightsV2:
         self.upd_w, self.upd_b = sd["track_feat_updater.0.weight"].contiguous(), sd["track_feat_updater.0.bias"].contiguous()
         self.upd_p = ops.pack_weight(self.upd_w) if split else None
         self.vis_w, self.vis_b = sd["vis_predictor.0.weight"].reshape(128).contiguous(), sd["vis_predictor.0.bias"].contiguous()
+        st = L.V2Weights()  # ctk_v2_weights of the one-call window driver (ctk_forward_window_v2)
+        st.former = fw
+        st.pos_hwc, st.pos_h, st.pos_w = self.pos_hwc.data_ptr(), self.pos_hwc.shape[0], self.pos_hwc.shape[1]
+        st.norm_w, st.norm_b = self.norm_w.data_ptr(), self.norm_b.data_ptr()
+        st.upd_w, st.upd_b = self.upd_w.data_ptr(), self.upd_b.data_ptr()
+        st.upd_p = self.upd_p.data_ptr() if self.upd_p is not None else None
+        st.vis_w, st.vis_b = self.vis_w.data_ptr(), self.vis_b.data_ptr()
+        self.struct = st
 
 
 def _v2_forward_window(self, pyr, coords, track_feat, vis, track_mask, point_mask, iters, pw):
-    """CoTracker2.forward_window (cotracker.py:86-173) for one batch element.  pyr: 4 x [S,H_l,W_l,128] (NOT normalised),
-    coords [S,N,2] feature units, track_feat [S,N,128] (already masked), vis [S,N], track_mask [S,N] float 0/1,
-    point_mask [N] uint8.  Returns (coords [S,N,2] feature units, vis logits [S,N])."""
-    S, N = coords.shape[0], coords.shape[1]
-    coords = coords.clone()
-    track_feat = track_feat.clone()
-    pos = ops.sample_features4d(pw.pos_hwc, coords[0].contiguous())  # sampled_pos_emb, :126-130
-    for _ in range(iters):
-        fcorrs = ops.corrblock_sample(pyr, track_feat, coords)                          # :134-137
-        x = ops.v2_assemble(coords, fcorrs, track_feat, track_mask, vis, pos, IN_LD, pw.split)   # :139-150
-        delta = ops.update_former_ex(x, pw.split, S, N, pw.former, point_mask)         # :152-155
-        normed = ops.v2_apply_delta(delta, coords, pw.norm_w, pw.norm_b, 1e-5)         # :157-159 + GroupNorm of :167
-        tf2 = track_feat.view(S * N, 128)
-        ops.gemm(normed, pw.upd_w, bias=pw.upd_b, act=L.ACT_GELU_ERF, resid=tf2, out=tf2, packed=pw.upd_p)  # :162-170
-    return coords, ops.v2_vis_head(track_feat, pw.vis_w, pw.vis_b)                      # :172
+    """CoTracker2.forward_window (cotracker.py:86-173) for one batch element: ONE C call (ctk_forward_window_v2), or one
+    hipGraph replay of it in streaming mode.  pyr: 4 x [S,H_l,W_l,128] (NOT normalised), coords [S,N,2] feature units,
+    track_feat [S,N,128] (already masked), vis [S,N], track_mask [S,N] float 0/1, point_mask [N] uint8.
+    Returns (coords [S,N,2] feature units, vis logits [S,N])."""
+    if getattr(self, "hip_graph", False) and getattr(self, "_online_active", False):
+        return self._graphed_window(pyr, coords, track_feat, vis, track_mask, point_mask, iters, pw)
+    win = ops.V2Window(pyr, coords.clone(), track_feat.clone(), vis.contiguous(), track_mask, point_mask, iters)
+    ops.forward_window_v2(win, pw)
+    return win.keep[1], win.vis_out
+
+
+def _v2_graphed_window(self, pyr, coords, track_feat, vis, track_mask, point_mask, iters, pw):
+    """Streaming: the whole window (iters x (5 + ~390) launches) is captured once per shape and replayed per chunk."""
+    key = (tuple(tuple(f.shape) for f in pyr), coords.shape[1], int(iters), id(pw), coords.device.index)
+    g = self._graphs.get(key)
+    if g is None:
+        if self._graphs:
+            torch.cuda.current_stream().synchronize()  # a replay of the graph being dropped may still be in flight
+        win = ops.V2Window([f.clone() for f in pyr], coords.clone(), track_feat.clone(), vis.clone(), track_mask.clone(),
+                           point_mask.clone(), iters)
+        g = ops.V2WindowGraph(win, pw)
+        self._graphs = {key: g}
+    else:
+        st_pyr, c_, tf_, v_, tm_, pm_ = g.win.keep
+        for d, s_ in zip(st_pyr, pyr):
+            d.copy_(s_)
+        c_.copy_(coords)
+        tf_.copy_(track_feat)
+        v_.copy_(vis)
+        tm_.copy_(track_mask)
+        pm_.copy_(point_mask)
+    g.launch()
+    return g.win.keep[1].clone(), g.win.vis_out.clone()
 
 
 def _v2_init_online(self):  # cotracker.py:187-191
@@ -179,6 +207,7 @@ def _v2_forward(self, video, queries, iters=4, is_train=False, is_online=False):
         assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
         if B != 1:
             raise NotImplementedError("online mode supports B=1")
+    self._online_active = bool(is_online)
     outs = [self._forward_one(video[b], queries[b], iters, is_online) for b in range(B)]
     return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), None
 
@@ -254,21 +283,26 @@ def _v2_packed(self, device):
 
 def _v2_invalidate(self):
     self._packed = None
+    if getattr(self, "_graphs", None):
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        self._graphs = {}  # captured graphs hold pointers into the old packed weights
 
 
 def _v2_load_state_dict(self, *args, **kwargs):
-    self._packed = None
+    _v2_invalidate(self)
     return nn.Module.load_state_dict(self, *args, **kwargs)
 
 
 def _v2_apply(self, fn, *args, **kwargs):
-    self._packed = None
+    _v2_invalidate(self)
     return nn.Module._apply(self, fn, *args, **kwargs)
 
 
 def _v2_getstate(self):  # the packed-weight cache holds ctypes structs with raw pointers: never pickled / deep-copied
     st = self.__dict__.copy()
     st["_packed"] = None
+    st["_graphs"] = {}
     return st
 
 
@@ -277,13 +311,14 @@ def _v2_deepcopy(self, memo):
     new = self.__class__.__new__(self.__class__)
     memo[id(self)] = new
     for k, v in self.__dict__.items():
-        new.__dict__[k] = None if k == "_packed" else copy.deepcopy(v, memo)
+        new.__dict__[k] = None if k == "_packed" else ({} if k == "_graphs" else copy.deepcopy(v, memo))
     return new
 
 
 CoTracker2.__getstate__ = _v2_getstate
 CoTracker2.__deepcopy__ = _v2_deepcopy
 CoTracker2.forward_window = _v2_forward_window
+CoTracker2._graphed_window = _v2_graphed_window
 CoTracker2.init_video_online_processing = _v2_init_online
 CoTracker2.forward = _v2_forward
 CoTracker2._forward_one = _v2_forward_one

@@ -261,6 +261,84 @@ def update_former_ex(x: torch.Tensor, x_split: bool, S: int, N: int, fw: "L.Form
                                      _stream()), "ctk_update_former_ex")
     return delta
 
+class V2Window:
+    """ctypes ctk_v2_window_args of one CoTracker2 window plus the tensors it points to (coords / track_feat are
+    updated in place by forward_window_v2, vis_out receives the visibility logits)."""
+
+    def __init__(self, pyr: Sequence[torch.Tensor], coords: torch.Tensor, track_feat: torch.Tensor, vis: torch.Tensor,
+                 track_mask: torch.Tensor, point_mask: Optional[torch.Tensor], iters: int):
+        _chk_f32(*pyr, coords, track_feat, vis, track_mask)
+        S, N = coords.shape[0], coords.shape[1]
+        assert coords.shape == (S, N, 2) and track_feat.shape == (S, N, 128) and vis.shape == (S, N) and track_mask.shape == (S, N)
+        a = L.V2WindowArgs()
+        a.S, a.N, a.iters = S, N, iters
+        for l in range(L.LEVELS):
+            assert pyr[l].shape[0] == S and pyr[l].shape[3] == 128
+            a.H[l], a.W[l], a.fmaps[l] = pyr[l].shape[1], pyr[l].shape[2], _ptr(pyr[l])
+        if point_mask is not None:
+            assert point_mask.dtype == torch.uint8 and point_mask.is_cuda and point_mask.shape == (N,)
+        self.vis_out = torch.empty(S, N, device=coords.device, dtype=torch.float32)
+        a.coords, a.track_feat, a.vis, a.track_mask = _ptr(coords), _ptr(track_feat), _ptr(vis), _ptr(track_mask)
+        a.point_mask, a.vis_out = _ptr(point_mask), _ptr(self.vis_out)
+        self.args = a
+        self.S, self.N = S, N
+        self.keep = (list(pyr), coords, track_feat, vis, track_mask, point_mask)
+        self.device = coords.device
+
+
+def forward_window_v2(win: V2Window, weights) -> None:
+    """CoTracker2.forward_window (cotracker.py:86-173) as one C call: `iters` iterations in place on win's coords /
+    track_feat, visibility logits into win.vis_out."""
+    lib = L.load()
+    nbytes = C.c_size_t(0)
+    L.check(lib.ctk_forward_window_v2_workspace_bytes(C.byref(win.args), C.byref(weights.struct), C.byref(nbytes)),
+            "ctk_forward_window_v2_workspace_bytes")
+    ws = _workspace(nbytes.value, win.device)
+    L.check(lib.ctk_forward_window_v2(C.byref(win.args), C.byref(weights.struct), _ptr(ws), ws.numel(), _stream()),
+            "ctk_forward_window_v2")
+
+
+class V2WindowGraph:
+    """hipGraph of one CoTracker2 window (ctk_v2_window_graph_create): same contract as WindowGraph -- pointers of the
+    window's tensors, the weights and a private workspace are baked in; refresh contents in place, then launch()."""
+
+    def __init__(self, win: V2Window, weights):
+        lib = L.load()
+        nbytes = C.c_size_t(0)
+        L.check(lib.ctk_forward_window_v2_workspace_bytes(C.byref(win.args), C.byref(weights.struct), C.byref(nbytes)),
+                "ctk_forward_window_v2_workspace_bytes")
+        self.win, self.weights = win, weights
+        self.ws = torch.empty(nbytes.value, device=win.device, dtype=torch.uint8)
+        # one direct iteration first so that every kernel's code object is resident (no lazy loads inside a capture)
+        state = (win.keep[1], win.keep[2])
+        saved = [t_.clone() for t_ in state]
+        iters, win.args.iters = win.args.iters, 1
+        L.check(lib.ctk_forward_window_v2(C.byref(win.args), C.byref(weights.struct), _ptr(self.ws), self.ws.numel(), _stream()),
+                "ctk_forward_window_v2")
+        win.args.iters = iters
+        for t_, s_ in zip(state, saved):
+            t_.copy_(s_)
+        torch.cuda.synchronize(win.device)
+        h = C.c_void_p()
+        L.check(lib.ctk_v2_window_graph_create(C.byref(win.args), C.byref(weights.struct), _ptr(self.ws), self.ws.numel(), C.byref(h)),
+                "ctk_v2_window_graph_create")
+        self._h = h
+        n = C.c_int64(0)
+        L.check(lib.ctk_window_graph_nodes(self._h, C.byref(n)), "ctk_window_graph_nodes")
+        self.nodes = n.value
+
+    def launch(self) -> None:
+        L.check(L.load().ctk_window_graph_launch(self._h, _stream()), "ctk_window_graph_launch")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                L.load().ctk_window_graph_destroy(h)
+            except Exception:
+                pass
+
+
 # ------------------------------------------------------------------------------------------
 # window-level ops
 # ------------------------------------------------------------------------------------------

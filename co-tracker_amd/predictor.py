@@ -23,8 +23,9 @@ def get_points_on_a_grid(size, extent, center=None, device="cpu"):
         return torch.tensor([W / 2, H / 2], device=device)[None, None]
     cy, cx = (H / 2, W / 2) if center is None else (float(center[0]), float(center[1]))
     m = W / 64
-    ys = torch.linspace(cy - H / 2 + m, cy + H / 2 - m, size, device=device)
-    xs = torch.linspace(cx - W / 2 + m, cx + W / 2 - m, size, device=device)
+    # endpoints in the reference's evaluation order (python doubles are not associative)
+    ys = torch.linspace(m - H / 2 + cy, H / 2 + cy - m, size, device=device)
+    xs = torch.linspace(m - W / 2 + cx, W / 2 + cx - m, size, device=device)
     gy, gx = torch.meshgrid(ys, xs, indexing="ij")
     return torch.stack([gx, gy], dim=-1).reshape(1, -1, 2)
 
@@ -156,8 +157,7 @@ class CoTrackerOnlinePredictor(torch.nn.Module):
         self.step = model.window_len // 2
         self.model = model
         self.model.eval()
-        if not v2:
-            self.model.hip_graph = True  # streaming: replay the captured window graph per chunk (configs[3])
+        self.model.hip_graph = True  # streaming: replay the captured window graph per chunk (configs[3])
 
     @torch.no_grad()
     def forward(self, video_chunk, is_first_step: bool = False, queries: torch.Tensor = None, grid_size: int = 5,

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 4
+#define CTK_ABI_VERSION 5
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -211,6 +211,36 @@ int ctk_v2_apply_delta(int32_t S, int32_t N, const float* delta, int32_t out_ld,
 int ctk_v2_vis_head(const float* track_feat, int64_t R, const float* w, const float* b, float* out, void* stream);
 int ctk_sample_features4d(const float* map, int32_t H, int32_t W, int32_t C, const float* coords, int32_t N, float* out,
                           void* stream);
+
+/* ---- CoTracker2 window driver: CoTracker2.forward_window (cotracker.py:86-173) as ONE capture-safe call per window
+ * (the CoTracker2 counterpart of ctk_forward_window): sampled positional embedding once, then `iters` x { CorrBlock
+ * sample -> token assembly -> update former (attention mask) -> coords += delta, GroupNorm(feature delta) ->
+ * track_feat += GELU(Linear(.)) }, then the visibility head.  coords and track_feat are updated IN PLACE.
+ * ctk_v2_window_graph_create captures one such call into a hipGraph (same ownership rules as ctk_window_graph_create;
+ * launch / nodes / destroy through the ctk_window_graph_* functions).                                               */
+typedef struct ctk_v2_window_args {
+  int32_t S, N, iters;
+  int32_t H[CTK_LEVELS], W[CTK_LEVELS];
+  const float* fmaps[CTK_LEVELS]; /* NHWC [S,H_l,W_l,128] CorrBlock pyramid, NOT normalised (blocks.py:300-307)  */
+  float* coords;                  /* [S,N,2] in/out, level-0 feature units                                       */
+  float* track_feat;              /* [S,N,128] in/out, already multiplied by the attention mask (cotracker.py:346) */
+  const float* vis;               /* [S,N] visibility logits fed to the former (constant over the iterations)    */
+  const float* track_mask;        /* [S,N] 0/1 as float (cotracker.py:338-344)                                   */
+  const uint8_t* point_mask;      /* [N] attention mask (cotracker.py:331-333) or NULL                           */
+  float* vis_out;                 /* [S,N] vis_predictor(track_feat) after the last iteration (cotracker.py:172) */
+} ctk_v2_window_args;
+typedef struct ctk_v2_weights {
+  ctk_former_weights former;      /* 6 + 6 layers, 456 -> 130 (in_ld / out_ld padded)                            */
+  const float* pos_hwc; int32_t pos_h, pos_w;  /* pos_emb as channels-last [pos_h,pos_w,456] (cotracker.py:60-66) */
+  const float* norm_w; const float* norm_b;    /* GroupNorm(1,128) (cotracker.py:79)                             */
+  const float* upd_w; const void* upd_p; const float* upd_b; /* track_feat_updater Linear 128->128 (f32 and/or packed) */
+  const float* vis_w; const float* vis_b;      /* vis_predictor Linear 128->1: [128], [1]                        */
+} ctk_v2_weights;
+int ctk_forward_window_v2_workspace_bytes(const ctk_v2_window_args* a, const ctk_v2_weights* w, size_t* out_bytes);
+int ctk_forward_window_v2(const ctk_v2_window_args* a, const ctk_v2_weights* w, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int ctk_v2_window_graph_create(const ctk_v2_window_args* a, const ctk_v2_weights* w, void* workspace,
+                               size_t workspace_bytes, ctk_window_graph** out);
 
 /* ---- Op D: standalone samplers --------------------------------------------------- */
 /* Integer floor indices (x0,y0) of the 7 x-taps and 7 y-taps of every (t,n,level), exactly as

@@ -294,10 +294,73 @@ def gen_cotracker2():
     save("cotracker2.npz", **out)
 
 
+@torch.no_grad()
+def gen_eval_predictor():
+    """EvaluationPredictor (evaluation_predictor.py:25-213), the TAP-Vid protocol front end: single-point mode (one model
+    call per query with its local 8x8 grid + the global 5x5 grid) and joint mode, on the offline model.
+    evaluation_predictor.py imports torchvision.transforms.Compose (unused; torchvision is absent here): a stub module
+    is registered for the import only -- the reference source is not touched."""
+    import types
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+    tvt.Compose = object
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    from cotracker.models.evaluation_predictor import EvaluationPredictor
+    out = {}
+    video = synthetic_video(8, 96, 128, seed=23)
+    q = torch.tensor([[[0.0, 30.0, 20.0], [2.0, 100.0, 70.0], [5.0, 64.0, 48.0]]])
+    torch.manual_seed(0)
+    m = CoTrackerThreeOffline(stride=4, corr_radius=3, window_len=60, model_resolution=(384, 512)).eval()
+    fill_synthetic_(m, seed=4)
+    for single in (True, False):
+        ev = EvaluationPredictor(m, grid_size=5, local_grid_size=8, single_point=single, n_iters=6)
+        tr, vi = ev(video, q)
+        out["single_tracks" if single else "joint_tracks"] = tr
+        out["single_vis" if single else "joint_vis"] = vi
+    save("eval_predictor.npz", video=video, queries=q, **out)
+
+
+@torch.no_grad()
+def gen_cotracker2_damped():
+    """CoTracker2 full forwards with DAMPED heads (head_scale 0.25) and 4 iterations per window: with the stress heads the
+    6+6-layer iteration is chaotic (see gen_cotracker2), with damped heads four iterations are pinnable at the
+    north-star tolerance.  The reference's own 1-vs-8-thread spread is stored next to the outputs."""
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(43)
+    video = synthetic_video(20, H, W, seed=4321)
+    q = _queries(g, 9, 14, H, W)
+    res = {}
+    for threads in (8, 1):
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        m = CoTracker2(stride=4, window_len=8, model_resolution=(H, W)).eval()
+        fill_synthetic_(m, seed=6, head_scale=0.25)
+        c, v, _ = m(video, q, iters=4)
+        m.init_video_online_processing()
+        for ind in range(0, video.shape[1] - 4, 4):
+            cs, vs, _ = m(video[:, ind:ind + 8], q, iters=4, is_online=True)
+        res[threads] = (c, v, cs, vs)
+    torch.set_num_threads(8)
+    c, v, cs, vs = res[8]
+    lg = lambda p: torch.log(p.double() / (1 - p.double()))  # noqa: E731
+    noise = dict(noise_coords=(res[8][0] - res[1][0]).abs().max(), noise_vis_logit=(lg(res[8][1]) - lg(res[1][1])).abs().max(),
+                 noise_stream_coords=(res[8][2] - res[1][2]).abs().max())
+    print("cotracker2 damped: reference 8 vs 1 threads", {k: float(x) for k, x in noise.items()},
+          "track motion", float((c - q[:, None, :, 1:]).abs().max()))
+    save("cotracker2_damped.npz", video=video, queries=q, coords=c, vis=v, stream_coords=cs, stream_vis=vs, **noise)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if sys.argv[1:] == ["predictor_modes"]:
         gen_predictor_modes()
+        sys.exit(0)
+    if sys.argv[1:] == ["eval_predictor"]:
+        gen_eval_predictor()
+        sys.exit(0)
+    if sys.argv[1:] == ["cotracker2_damped"]:
+        gen_cotracker2_damped()
         sys.exit(0)
     gen_sampler()
     gen_ops()
@@ -306,3 +369,5 @@ if __name__ == "__main__":
     gen_predictor_modes()
     gen_corrblock()
     gen_cotracker2()
+    gen_cotracker2_damped()
+    gen_eval_predictor()

@@ -23,28 +23,52 @@ def test_default_workload_is_the_baseline_config():
     assert (a.gpus, a.workload, a.precision) == (1, "c3_sliding", "f16x3") and a.steps >= 1 and a.warmup >= 1
 
 
-def test_roofline_entry_split_half_and_traffic():
-    row = {"name": "gemm_sh_128x128", "launches": 10, "total_ms": 4.0, "flops": 1.0e12, "bytes": 8.0e9}
-    traffic = {"gemm_sh_128x128": {"hbm_bytes_per_launch": 9.0e8, "fetch_bytes_per_launch": 6e8, "write_bytes_per_launch": 3e8,
-                                   "dispatches": 10, "source": "test"}}
-    r = bench.roofline_entry(row, traffic)
+def test_roofline_objects():
+    row = {"name": "gemm_sh_128_k384_n384", "launches": 10, "total_ms": 4.0, "flops": 1.0e12, "bytes": 8.0e9}
+    traffic = {row["name"]: {"hbm_bytes_per_launch": 9.0e8, "fetch_bytes_per_launch": 6e8, "write_bytes_per_launch": 3e8,
+                             "dispatches": 10, "source": "test"}}
+    r = bench.roofline_mfma(row["name"], [row], traffic)
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
     assert abs(r["achieved"] - 250.0) < 1e-6 and abs(r["peak"] - 833.3) < 0.1     # 1e12 flop / 4 ms; 2500 / 3
     assert abs(r["frac"] - 250.0 / r["peak"]) < 1e-3 and r["mfma_issued"] == 750.0
     assert r["avg_launch_us"] == 400.0 and r["traffic"] == 9.0e8
-    r32 = bench.roofline_entry(dict(row, name="gemm_f32_128x128"), {})
+    r32 = bench.roofline_mfma("gemm_f32_128x128", [dict(row, name="gemm_f32_128x128")], {})
     assert r32["peak"] == 157.3 and r32["traffic"] is None
-    hbm = bench.roofline_entry(dict(row, name="corr_volume_sh"), {}, force_hbm=True)
-    assert hbm["bound"] == "hbm" and hbm["unit"] == "GB/s" and abs(hbm["achieved"] - 2000.0) < 1e-6 and hbm["peak"] == 8000.0
+    both = bench.roofline_mfma("gemm (all Linear launches, call-weighted)", [row, dict(row, total_ms=12.0)], traffic)
+    assert abs(both["achieved"] - 2.0e12 / 16e-3 / 1e12) < 1e-6 and both["launches"] == 20 and both["traffic"] is None
+    # the sampler is priced against max(measured HBM time, MFMA time), never against its no-reuse algorithmic bytes
+    srow = {"name": "corr_volume_sh", "launches": 2, "total_ms": 5.6, "flops": 2 * 2.52e11, "bytes": 2 * 1.8e10}
+    st = {"corr_volume_sh": {"hbm_bytes_per_launch": 5.94e9, "fetch_bytes_per_launch": 2.22e9, "write_bytes_per_launch": 3.72e9}}
+    s_ = bench.roofline_sampler(srow, st)
+    assert s_["bound"] == "hbm" and abs(s_["frac"] - (5.94e9 / 8e12) / 2.8e-3) < 1e-3 and abs(s_["hbm_frac"] - 0.2652) < 1e-3
+    assert s_["algorithmic_GBs_no_reuse"] > 6000 and s_["mfma_frac"] < 0.12
+    assert bench.roofline_sampler(srow, {})["bound"] == "mfma"  # no PMC pass: HBM side unknown, say so
+    assert "unmeasured" in bench.roofline_sampler(srow, {})["note"]
 
 
-def test_cpu_baseline_is_the_oracle_on_a_bounded_sample():
-    cb = bench.cpu_baseline(8, 224 / 120, n_points=4, reps=1)  # 8 frames x 4 points keeps this test at a few seconds
-    assert cb["kind"] == "port" and cb["unit"] == "tracked-point-frames/s" and cb["cores"] >= 1 and cb["value"] > 0
-    assert "numpy oracle" in cb["sample"]
+def test_cpu_baseline_is_the_torch_port_on_a_bounded_sample(monkeypatch):
+    """The baseline leg runs oracle/torch_port.py in a subprocess (ATen CPU kernels, encoder included); here on the
+    smoke-sized workload so the CPU suite stays short."""
+    monkeypatch.setitem(bench.WORKLOADS, "tiny_cpu", (64, 64, 8, 3, True, 60, "test"))
+    import oracle.torch_port as TP
+    r = TP.bench("offline", 6, 3, 64, 2)
+    assert r["tracked_point_frames_per_s"] > 0 and r["points"] == 9 and r["threads"] == 2
+    base = bench.cpu_baseline("c2_offline") if os.environ.get("CTK_SLOW_TESTS") else None
+    if base is not None:
+        assert base["kind"] == "port-torch" and base["value"] > 0
+
+
+def test_workload_table_covers_every_baseline_config():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "70225" in base["configs"][4] and bench.WORKLOADS["c5_shard"][3] == 265
+    from cotracker_amd.sharding import chunk_bounds
+    assert chunk_bounds(265 * 265, 8, 0) == (0, 8779)
+    for name in ("c2_offline", "c3_sliding", "c4_online", "c5_shard"):
+        assert name in bench.WORKLOADS
 
 
 def test_committed_pmc_traffic_is_tagged_with_its_workload():
     d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert d["_workload"] == "c3_sliding"
-    assert d["gemm_sh_128x128"]["hbm_bytes_per_launch"] > 0 and "FETCH_SIZE x2" in d["gemm_sh_128x128"]["source"]
+    rows = [v for k, v in d.items() if k.startswith("gemm_sh")]
+    assert rows and rows[0]["hbm_bytes_per_launch"] > 0 and "FETCH_SIZE x2" in rows[0]["source"]

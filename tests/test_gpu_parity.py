@@ -639,6 +639,29 @@ def test_predictor_dense_mode_and_segm_mask(golden):
     assert (vi.cpu().numpy() != g["segm_vis"]).mean() < 1e-2
 
 
+def test_evaluation_predictor(golden):
+    """EvaluationPredictor (the TAP-Vid protocol front end, evaluation_predictor.py:50-144): single-point mode (one
+    call per query + local / global support grids) and joint mode vs the reference's outputs."""
+    import os
+    from cotracker_amd.evaluation import EvaluationPredictor
+    from cotracker_amd.model import CoTrackerThreeOffline
+    from cotracker_amd.weights import fill_synthetic_
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "eval_predictor.npz")):
+        pytest.skip("eval_predictor.npz not generated")
+    g = golden("eval_predictor")
+    m = CoTrackerThreeOffline(stride=4, corr_radius=3, window_len=60, model_resolution=(384, 512)).eval()
+    fill_synthetic_(m, seed=4)
+    m = m.to(dev())
+    video, q = t(g["video"]), t(g["queries"])
+    for single in (True, False):
+        ev = EvaluationPredictor(m, grid_size=5, local_grid_size=8, single_point=single, n_iters=6)
+        tr, vi = ev(video, q)
+        k = "single" if single else "joint"
+        assert tr.shape == g[k + "_tracks"].shape and vi.shape == g[k + "_vis"].shape
+        assert maxdiff(tr, g[k + "_tracks"]) < 1e-3
+        assert maxdiff(vi, g[k + "_vis"]) < 1e-4  # visibility * confidence, both post-sigmoid (<= 1)
+
+
 def test_full_size_properties():
     """Size-independent properties at C3's window shape (S=16, N=6400): determinism, independence of
     the point-chunking of the correlation stage, and zero update for masked-off support."""
@@ -779,6 +802,63 @@ def test_cotracker2_model_sliding_and_streaming(golden, precision):
         cs, vs, _ = m(video[:, ind:ind + 8], q, iters=1, is_online=True)
     assert maxdiff(cs, g["stream_coords"]) < 1e-3
     assert maxdiff(logit(vs), logit(g["stream_vis"])) < 2e-4
+
+
+def test_cotracker2_damped_heads_four_iterations(golden, precision):
+    """CoTracker2 at the north-star tolerance over FOUR iterations per window (sliding and streaming), on weights whose
+    heads are damped (head_scale 0.25) so that the iteration is contractive instead of chaotic: 1e-3 px / 1e-4 logit."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "cotracker2_damped.npz")):
+        pytest.skip("cotracker2_damped.npz not generated")
+    from cotracker_amd.model_v2 import CoTracker2
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("cotracker2_damped")
+    m = CoTracker2(stride=4, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=6, head_scale=0.25)
+    m = m.to(dev())
+    assert m.precision == precision
+    video, q = t(g["video"]), t(g["queries"])
+    c, v, _ = m(video, q, iters=4)
+    assert maxdiff(c, g["coords"]) < 1e-3
+    assert maxdiff(logit(v), logit(g["vis"])) < 1e-4
+    for use_graph in (False, True):
+        m.hip_graph = use_graph
+        m.init_video_online_processing()
+        for ind in range(0, video.shape[1] - 4, 4):
+            cs, vs, _ = m(video[:, ind:ind + 8], q, iters=4, is_online=True)
+        assert maxdiff(cs, g["stream_coords"]) < 1e-3
+        assert maxdiff(logit(vs), logit(g["stream_vis"])) < 1e-4
+        assert bool(m._graphs) == use_graph
+    assert next(iter(m._graphs.values())).nodes > 1000  # 4 iterations x ~390 launches in ONE graph
+
+
+def test_cotracker2_window_graph_replay_is_bit_identical(golden, precision):
+    """ctk_v2_window_graph_create: the captured CoTracker2 window replays the same launches as the direct call."""
+    from cotracker_amd import ops
+    g = golden("cotracker2")
+    m = _v2_model(precision)
+    pw = m.packed(dev())
+    S, N = g["fw_coords"].shape[1], g["fw_coords"].shape[2]
+    fm = t(np.transpose(g["fw_fmaps"][0], (0, 2, 3, 1)))
+    pyr = ops.build_pyramid(fm.contiguous(), 4)
+    amask = t(g["fw_attention_mask"][0, 0].astype(np.uint8))
+    tf = (t(g["fw_track_feat"][0]) * amask.float()[None, :, None]).contiguous()
+    tm = t(g["fw_track_mask"][0, ..., 0].astype(np.float32))
+    vis = t(g["fw_vis"][0, ..., 0])
+    direct = []
+    for shift in (0.0, 0.4):
+        win = ops.V2Window(pyr, t(g["fw_coords"][0]) + shift, tf.clone(), vis, tm, amask, 3)
+        ops.forward_window_v2(win, pw)
+        direct.append((win.keep[1].clone(), win.keep[2].clone(), win.vis_out.clone()))
+    win = ops.V2Window(pyr, t(g["fw_coords"][0]).clone(), tf.clone(), vis, tm, amask, 3)
+    gr = ops.V2WindowGraph(win, pw)
+    assert gr.nodes > 500
+    for k, shift in enumerate((0.0, 0.4)):
+        win.keep[1].copy_(t(g["fw_coords"][0]) + shift)
+        win.keep[2].copy_(tf)
+        gr.launch()
+        for a, b in zip((win.keep[1], win.keep[2], win.vis_out), direct[k]):
+            assert maxdiff(a, b) == 0.0
 
 
 def test_cotracker2_predictor_runs():

@@ -227,3 +227,37 @@ def test_cotracker2_model_sliding_and_streaming():
         cs, vs = O.model_forward_v2(fm[:, ind:ind + 8], g["queries"], p, window_len=8, iters=1, is_online=True, state=st)
     assert np.abs(cs - g["stream_coords"]).max() < 1e-3
     assert np.abs(_logit(vs) - _logit(g["stream_vis"])).max() < 2e-4
+
+
+# ---- torch-CPU port (oracle/torch_port.py): the CPU baseline bench.py times -------------------------------
+def test_torch_port_matches_reference_goldens(golden):
+    """The port calls the same ATen kernels in the same order as the reference, so it reproduces the reference's
+    model-level outputs (sliding windows incl. the carry-over logic, and the offline single window) to fp32 noise."""
+    import torch
+    from oracle import torch_port as TP
+    from cotracker_amd.model import CoTrackerThreeOnline, CoTrackerThreeOffline
+    from cotracker_amd.weights import fill_synthetic_
+
+    def params(m):
+        return m.fnet, {k: v for k, v in m.state_dict().items() if not k.startswith("fnet.")}
+
+    def lg(p):
+        p = torch.from_numpy(np.asarray(p)).double()
+        return torch.log(p / (1 - p))
+
+    g = golden("model_online")
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=1)
+    fnet, p = params(m)
+    c, v, f = TP.model_forward(fnet, p, torch.from_numpy(g["on_video"]), torch.from_numpy(g["on_queries"]), iters=4, window_len=8)
+    assert float((c - torch.from_numpy(g["on_coords"])).abs().max()) < 2e-4
+    assert float((v.double() - lg(g["on_vis"])).abs().max()) < 1e-4
+    assert float((f.double() - lg(g["on_conf"])).abs().max()) < 1e-4
+
+    g = golden("model_offline")
+    m = CoTrackerThreeOffline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=2)
+    fnet, p = params(m)
+    c, v, f = TP.model_forward(fnet, p, torch.from_numpy(g["off_video"]), torch.from_numpy(g["off_queries"]), iters=4, offline=True)
+    assert float((c - torch.from_numpy(g["off_coords"])).abs().max()) < 2e-4
+    assert float((v.double() - lg(g["off_vis"])).abs().max()) < 1e-4
