@@ -241,6 +241,7 @@ class CoTrackerThreeBase(nn.Module):
         # exact-f32 MFMA back end of the same library (fp32 range, as the reference).  range_fallbacks counts hits.
         self.range_guard = True
         self.range_fallbacks = 0
+        self.encoder_dtype = torch.float32  # fp32 as the reference; see tools/probe_encoder_precision.py for why not lower
         # pre-sigmoid (visibility, confidence) of the last forward, [B,T,N] each -- parity tests compare logits
         self.last_logits = None
 
@@ -341,7 +342,12 @@ class CoTrackerThreeBase(nn.Module):
         outs = []
         for t0 in range(0, frames.shape[0], chunk):
             x = 2 * (frames[t0:t0 + chunk] / 255.0) - 1.0  # cotracker3_online.py:320
-            outs.append(ops.normalize_to_nhwc(self.fnet(x).float().contiguous()))
+            if self.encoder_dtype == torch.float32:
+                f = self.fnet(x)
+            else:  # experiment knob (tools/probe_encoder_precision.py): MIOpen convolutions in half precision
+                with torch.autocast("cuda", dtype=self.encoder_dtype):
+                    f = self.fnet(x)
+            outs.append(ops.normalize_to_nhwc(f.float().contiguous()))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     def _support(self, pyr, frames_f: torch.Tensor, qcoords: torch.Tensor):
