@@ -48,6 +48,7 @@ class WindowArgs(C.Structure):
         ("coords", _fp), ("vis", _fp), ("conf", _fp),
         ("scale_x", C.c_float), ("scale_y", C.c_float),
         ("points_per_chunk", C.c_int32),
+        ("aux_stream", _fp),
     ]
 
 

@@ -2,6 +2,8 @@
 // -> heads + state update, all enqueued on the caller's stream (no host sync, capturable).
 #include "ctk_common.h"
 #include "ctk_profile.h"
+#include <cstdlib>
+#include <mutex>
 #include <new>
 
 int ctk_launch_corr_volume(const ctk_window_args* a, int n0, int ncount, float* out, long level_stride, int ld,
@@ -22,6 +24,56 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
     int rc__ = (expr);       \
     if (rc__) return rc__;   \
   } while (0)
+
+// ---- two-stream overlap (ctk_window_args.aux_stream) --------------------------------------------------------
+// Fork / join between the caller's stream and its auxiliary stream use timing-less events from a small ring.  An event
+// may be re-recorded as soon as the hipStreamWaitEvent that consumes its previous record has been ENQUEUED (the wait
+// binds to the record that precedes it), so a ring far longer than one fork/join sequence needs no host synchronisation.
+// The events are host objects created on first use and kept for the life of the process (the second exception, after
+// the profiler, to "no mutable global state"); both calls are legal during stream capture, where they become graph edges
+// and pull the auxiliary stream into the capture.
+class EventRing {
+ public:
+  hipEvent_t next() {
+    std::lock_guard<std::mutex> g(m_);
+    if (!ready_) {
+      for (auto& e : ev_) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      ready_ = true;
+    }
+    hipEvent_t e = ev_[i_];
+    i_ = (i_ + 1) % kN;
+    return e;
+  }
+
+ private:
+  static constexpr int kN = 256;
+  std::mutex m_;
+  hipEvent_t ev_[kN];
+  int i_ = 0;
+  bool ready_ = false;
+};
+EventRing g_events;
+
+// `to` waits for everything enqueued on `from` so far
+int stream_follow(hipStream_t from, hipStream_t to) {
+  hipEvent_t e = g_events.next();
+  hipError_t rc = hipEventRecord(e, from);
+  if (rc != hipSuccess) return (int)rc;
+  rc = hipStreamWaitEvent(to, e, 0);
+  return rc == hipSuccess ? CTK_OK : (int)rc;
+}
+
+// Knob CTK_OVERLAP (read per call): 0 = ignore aux_stream (everything on the caller's stream), bit 1 = software
+// pipeline sampler || corr_mlp, bit 2 = points<-virtual query projection beside the virtual-track chain.
+// DEFAULT 0: measured on MI355X at C3 (profiles/r02_overlap_and_time_attention_ab.txt) the sampler and the corr_mlp GEMM
+// do NOT complement each other -- run side by side each slows down by more than the other gains (sampler 2.70 -> 4 x
+// 1.21 ms, fc1 2.24 -> 4 x 0.77 ms per iteration; step 1528.5 -> 1547.3 ms) -- and the side query projection is worth
+// 0.15 % (1526.1 ms), inside run-to-run noise.  Results are bit-identical in every mode (tests), so the code stays
+// as an opt-in for other shapes.
+int overlap_mode() {
+  const char* e = getenv("CTK_OVERLAP");
+  return e ? atoi(e) : 0;
+}
 
 // A Linear's weight: torch-layout f32 and/or the ctk_pack_weight blob (preferred when present).
 struct WRef {
@@ -50,6 +102,7 @@ bool split_mode(const ctk_model_weights* w) { return w->in_p != nullptr; }
 struct UfWs {
   float* tokens;  // [R,384]
   float* xn;      // [R,384]
+  float* xn2;     // [N*S,384]  norm1(points) of the points<-virtual block, produced on the auxiliary stream
   float* qkv;     // [R,1152]
   float* att;     // [R,384]
   float* hid;     // [R,1536]
@@ -76,6 +129,7 @@ UfWs carve_uf(int S, int N, void* base) {
   };
   w.tokens = take(R * CTK_HID);
   w.xn = take(R * CTK_HID);
+  w.xn2 = take((size_t)N * S * CTK_HID);
   w.qkv = take(R * 3 * CTK_HID);
   w.att = take(R * CTK_HID);
   w.hid = take(R * CTK_MLP);
@@ -128,11 +182,12 @@ struct FormerRef {
   const float* virtual_tokens;
   const uint8_t* point_mask;  // CoTracker2 attention_mask per point (cotracker.py:343-345) or null
   bool split;                 // xn / att / hid are SH-format (split-half back end)
+  hipStream_t aux;            // optional second stream (ctk_window_args.aux_stream) or null
 };
 
 FormerRef former_of(const ctk_model_weights* w) {
   return FormerRef{CTK_DEPTH, w->time_blocks, w->virtual2point, w->virtual_self, w->point2virtual, w->virtual_tokens, nullptr,
-                   w->in_p != nullptr};
+                   w->in_p != nullptr, nullptr};
 }
 
 // EfficientUpdateFormer.forward (cotracker.py:483-531) on tokens already holding the input
@@ -160,6 +215,17 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
       CTK_TRY(attn(qkv, QL, S, 1, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, S, 1, att, S, 1, N + CTK_VIRT, S, S, 1, nullptr, s, sp));
       CTK_TRY(gemm(att, CTK_HID, (int)R, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(mlp_block(ws, 0, R, b, s, sp));
+    }
+    // The points<-virtual block's query side -- norm1(points) and to_q(points) -- depends only on the point tokens the
+    // time block just produced, not on the virtual tracks: with an auxiliary stream it runs BESIDE the virtual-track
+    // chain below (virtual<-points attention, two 1024-row MLPs, virtual self attention: ~16 launches that occupy a
+    // fraction of the chip), into its own xn2 buffer and the (otherwise unused) q columns of the point rows of qkv.
+    const bool side_q = fr.aux != nullptr && (overlap_mode() & 2) != 0;
+    if (side_q) {
+      const ctk_block_weights& b = w->point2virtual[i];
+      CTK_TRY(stream_follow(s, fr.aux));
+      CTK_TRY(ctk_layernorm(tok, ws.xn2, P, nullptr, nullptr, 1e-6f, sp, fr.aux));                                          // norm1(points)
+      CTK_TRY(gemm(ws.xn2, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, fr.aux, nullptr, 0, 1, 0, 0, 0, sp, false));
     }
     // ---- virtual <- points cross attention                          cotracker.py:510-512
     {
@@ -190,9 +256,10 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     // ---- points <- virtual cross attention                          cotracker.py:515-517
     {
       const ctk_block_weights& b = w->point2virtual[i];
-      CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, sp, s));                                              // norm1(points)
+      if (!side_q) CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, sp, s));                                 // norm1(points)
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));           // norm_context(virtual)
-      CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      if (!side_q) CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      else CTK_TRY(stream_follow(fr.aux, s));  // join: q(points) is ready
       CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s, sp,
                    nullptr, fr.point_mask));  // mask over QUERIES (cotracker.py:561-564)
@@ -276,17 +343,37 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
   const bool sp = split_mode(w);
   if (x_split && !sp) return CTK_E_SHAPE;
   if ((!w->corr_fc1_w && !w->corr_fc1_p) || !w->corr_fc1_b || (!w->corr_fc2_w && !w->corr_fc2_p) || !w->corr_fc2_b) return CTK_E_NULL;
+  hipStream_t aux = static_cast<hipStream_t>(a->aux_stream);
+  const bool pipelined = sp && aux != nullptr && (overlap_mode() & 1) != 0;
   for (int n0 = 0; n0 < a->N; n0 += ws.chunk) {
     const int cnt = (a->N - n0 < ws.chunk) ? a->N - n0 : ws.chunk;
-    const long rows = (long)cnt * a->S;
-    if (sp) CTK_TRY(ctk_launch_corr_volume_sh(a, ws.fm_sh, n0, cnt, ws.vol, rows * CTK_CORR_LD * 2, s));
-    else CTK_TRY(ctk_launch_corr_volume(a, n0, cnt, ws.vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
-    // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
-    CTK_TRY(gemm(ws.vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), WRef{w->corr_fc1_w, w->corr_fc1_p}, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, ws.h1, CTK_HID,
-                 w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, s, nullptr, 0, 1, 0, 0, CTK_CORR_K, sp, sp));
-    // corr_mlp.fc2, one batch per level, written into x[n*S+t][l*256 ...]   (torch.cat :209)
-    CTK_TRY(gemm(ws.h1, CTK_HID, (int)rows, WRef{w->corr_fc2_w, w->corr_fc2_p}, CTK_HID, 256, CTK_HID, x + (long)n0 * a->S * CTK_X_LD + CTK_X_CORR,
-                 CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256, 0, sp, x_split));
+    // Software pipeline over point pieces: the sampler (VALU / LDS bound, MFMA pipe ~11 % busy) of piece j+1 runs on the
+    // caller's stream while corr_mlp of piece j (MFMA bound) runs on the auxiliary stream; one workgroup of each kind
+    // fits on a CU (77 KiB + 64 KiB of LDS).  Each piece has its own slice of the volume / hidden buffers.
+    const int pieces = pipelined ? ((cnt >= 4096) ? 4 : (cnt >= 1024 ? 2 : 1)) : 1;
+    const int per = (cnt + pieces - 1) / pieces;
+    for (int j = 0; j < pieces; ++j) {
+      const int p0 = j * per;
+      const int pc = (cnt - p0 < per) ? cnt - p0 : per;
+      if (pc <= 0) break;
+      const long rows = (long)pc * a->S;
+      float* vol = ws.vol + (size_t)p0 * a->S * CTK_LEVELS * CTK_CORR_LD;
+      float* h1 = ws.h1 + (size_t)p0 * a->S * CTK_LEVELS * CTK_HID;
+      hipStream_t gs = s;
+      if (sp) CTK_TRY(ctk_launch_corr_volume_sh(a, ws.fm_sh, n0 + p0, pc, vol, rows * CTK_CORR_LD * 2, s));
+      else CTK_TRY(ctk_launch_corr_volume(a, n0 + p0, pc, vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
+      if (pipelined && pieces > 1) {
+        CTK_TRY(stream_follow(s, aux));
+        gs = aux;
+      }
+      // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
+      CTK_TRY(gemm(vol, CTK_CORR_LD, (int)(rows * CTK_LEVELS), WRef{w->corr_fc1_w, w->corr_fc1_p}, CTK_CORR_LD, CTK_HID, CTK_CORR_LD, h1, CTK_HID,
+                   w->corr_fc1_b, CTK_ACT_GELU_ERF, nullptr, 0, gs, nullptr, 0, 1, 0, 0, CTK_CORR_K, sp, sp));
+      // corr_mlp.fc2, one batch per level, written into x[n*S+t][l*256 ...]   (torch.cat :209)
+      CTK_TRY(gemm(h1, CTK_HID, (int)rows, WRef{w->corr_fc2_w, w->corr_fc2_p}, CTK_HID, 256, CTK_HID, x + (long)(n0 + p0) * a->S * CTK_X_LD + CTK_X_CORR,
+                   CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, gs, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256, 0, sp, x_split));
+    }
+    if (pipelined && pieces > 1) CTK_TRY(stream_follow(aux, s));  // join before the next chunk reuses the buffers / x is consumed
   }
   return CTK_OK;
 }
@@ -360,7 +447,7 @@ extern "C" int ctk_update_former_ex(int32_t S, int32_t N, const void* x, int32_t
   // tokens = input_transform(x) (+ per-frame bias rows = W e_t + b when in_bias_t is given, else + in_b)
   CTK_TRY(gemm(static_cast<const float*>(x), w->in_ld, N * S, WRef{w->in_w, w->in_p}, w->in_ld, CTK_HID, w->in_ld, ws.tokens, CTK_HID,
                w->in_bias_t ? nullptr : w->in_b, CTK_ACT_NONE, nullptr, 0, s, w->in_bias_t, S, 1, 0, 0, w->in_dim, x_split != 0, false));
-  const FormerRef fr{w->depth, w->time_blocks, w->virtual2point, w->virtual_self, w->point2virtual, w->virtual_tokens, point_mask, sp};
+  const FormerRef fr{w->depth, w->time_blocks, w->virtual2point, w->virtual_self, w->point2virtual, w->virtual_tokens, point_mask, sp, nullptr};
   CTK_TRY(run_transformer(S, N, fr, ws, s));
   // heads: delta[n*S+t][0..out_ld) = tokens @ head_w^T + head_b   (flow_head, cotracker.py:526)
   return gemm(ws.tokens, CTK_HID, N * S, WRef{w->head_w, w->head_p}, CTK_HID, w->out_ld, CTK_HID, delta, w->out_ld, w->head_b, CTK_ACT_NONE,
@@ -433,7 +520,9 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
     CTK_TRY(run_corr_embed(a, w, x, sp, cws, s));               // :190-210
     CTK_TRY(ctk_assemble_tokens(a, x, sp, s));                  // :212-245
     CTK_TRY(input_projection(a->S, a->N, x, sp, w, uws, s));    // :247 + cotracker.py:484
-    CTK_TRY(run_transformer(a->S, a->N, former_of(w), uws, s)); // :250
+    FormerRef fr = former_of(w);
+    fr.aux = static_cast<hipStream_t>(a->aux_stream);
+    CTK_TRY(run_transformer(a->S, a->N, fr, uws, s));           // :250
     CTK_TRY(ctk_launch_heads(uws.tokens, w->head_w, w->head_b, a->S, a->N, nullptr, a->coords, a->vis, a->conf, s));  // :252-259
   }
   return CTK_OK;

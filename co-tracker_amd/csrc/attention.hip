@@ -664,6 +664,138 @@ __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
   }
 }
 
+// ---- time attention, S <= 16, no masks (CoTracker3 sliding / streaming): persistent waves with register prefetch ---
+// attention_self_kernel<2> is latency bound: at 2 waves per SIMD a wave loads its q / k / v rows (18 KB), waits, splits,
+// runs 63 MFMAs and exits -- 204 us per launch at C3 where the MFMAs alone would take ~25 us.  Here a wave walks over
+// jobs (batch pair, head) with a stride of the whole grid and issues the NEXT job's raw f32 loads before it splits and
+// multiplies the current one, so the memory latency of job i+1 hides behind the arithmetic of job i.  Jobs are numbered
+// head-fastest: neighbouring waves read neighbouring 192-byte head slices of the same token rows.  The arithmetic (split,
+// MFMA order, log2-domain softmax) is that of attention_self_kernel<2>, instruction for instruction: same bits out.
+struct TimeRaw {
+  f32x4 q[6], k[6];
+  float v0[16], v1[16];
+};
+
+__global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long njobs) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r32 = lane & 31, half = lane >> 5;
+  const long stride = (long)gridDim.x * 4;
+  long job = (long)blockIdx.x * 4 + wave;
+  if (job >= njobs) return;  // wave-uniform
+  const int vd0 = r32, vd1 = min(32 + r32, HD - 1);
+  const int rb = r32 >> 4, ri = r32 & 15;  // batch of the pair / frame slot of my q and k row
+
+  auto load = [&](long jb, TimeRaw& r) {
+    const int head = (int)(jb % CTK_HEADS);
+    const int b0 = (int)(jb / CTK_HEADS) * 2;
+    const int bc = min(b0 + rb, p.nbatch - 1), ic = min(ri, p.n1 - 1);
+    const float* qp = p.q + ((long)bc * p.q_bs + (long)ic * p.q_is) * p.q_ld + head * HD + half * 8;
+    const float* kp = p.k + ((long)bc * p.kv_bs + (long)ic * p.kv_is) * p.kv_ld + head * HD + half * 8;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      r.q[2 * j] = *reinterpret_cast<const f32x4*>(qp + 16 * j);
+      r.q[2 * j + 1] = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4);
+      r.k[2 * j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
+      r.k[2 * j + 1] = *reinterpret_cast<const f32x4*>(kp + 16 * j + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int slot = 16 * s + 8 * (e >> 2) + 4 * half + (e & 3);
+        const int kb = min(b0 + (slot >> 4), p.nbatch - 1), ki = min(slot & 15, p.n2 - 1);
+        const float* vp = p.v + ((long)kb * p.kv_bs + (long)ki * p.kv_is) * p.kv_ld + head * HD;
+        r.v0[8 * s + e] = vp[vd0];
+        r.v1[8 * s + e] = vp[vd1];
+      }
+  };
+
+  TimeRaw raw;
+  load(job, raw);
+  while (true) {
+    const int head = (int)(job % CTK_HEADS);
+    const int b0 = (int)(job / CTK_HEADS) * 2;
+    // raw f32 -> split-half fragments (the raw registers are dead afterwards and take the next job's loads)
+    f16x8 qh[3], ql[3], kh[3], kl[3], vh[2][2], vl[2][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ctk_split8(raw.q[2 * j] * p.scale2, raw.q[2 * j + 1] * p.scale2, qh[j], ql[j]);
+      ctk_split8(raw.k[2 * j], raw.k[2 * j + 1], kh[j], kl[j]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ctk_split8(f32x4{raw.v0[8 * s], raw.v0[8 * s + 1], raw.v0[8 * s + 2], raw.v0[8 * s + 3]},
+                 f32x4{raw.v0[8 * s + 4], raw.v0[8 * s + 5], raw.v0[8 * s + 6], raw.v0[8 * s + 7]}, vh[0][s], vl[0][s]);
+      ctk_split8(f32x4{raw.v1[8 * s], raw.v1[8 * s + 1], raw.v1[8 * s + 2], raw.v1[8 * s + 3]},
+                 f32x4{raw.v1[8 * s + 4], raw.v1[8 * s + 5], raw.v1[8 * s + 6], raw.v1[8 * s + 7]}, vh[1][s], vl[1][s]);
+    }
+    const long next = job + stride;
+    const bool more = next < njobs;  // wave-uniform
+    if (more) load(next, raw);
+
+    const bool qvalid = (b0 + rb < p.nbatch) && (ri < p.n1);
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sacc = ctk_mma3(kh[j], kl[j], qh[j], ql[j], sacc);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int slot = 8 * (e >> 2) + 4 * half + (e & 3);
+      const bool ok = ((slot >> 4) == rb) && (b0 + (slot >> 4) < p.nbatch) && ((slot & 15) < p.n2);
+      sacc[e] = ok ? sacc[e] : -INFINITY;
+      tmax = fmaxf(tmax, sacc[e]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = (tmax == -INFINITY) ? 0.0f : tmax;  // padding slot: all probabilities 0, never stored
+    float l = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = __builtin_amdgcn_exp2f(sacc[e] - mnew);
+      l += pv;
+      sacc[e] = pv * PSCALE;
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 ph, pl;
+      ctk_split8(f32x4{sacc[8 * s], sacc[8 * s + 1], sacc[8 * s + 2], sacc[8 * s + 3]},
+                 f32x4{sacc[8 * s + 4], sacc[8 * s + 5], sacc[8 * s + 6], sacc[8 * s + 7]}, ph, pl);
+      oacc[0] = ctk_mma3(vh[0][s], vl[0][s], ph, pl, oacc[0]);
+      oacc[1] = ctk_mma3(vh[1][s], vl[1][s], ph, pl, oacc[1]);
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (qvalid) {
+      const float inv = 1.0f / (l * PSCALE);
+      const long orow = ((long)(b0 + rb) * p.o_bs + (long)ri * p.o_is) * p.o_ld;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int d = dt * 32 + q * 8 + half * 4;
+          if (d < HD) {
+            const f32x4 t = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
+            if (p.o_split) {
+              f16x4 hi, lo;
+              ctk_split4(t, hi, lo);
+              _Float16* dst = reinterpret_cast<_Float16*>(p.out) + orow + ctk_sh_col(head * HD + d);
+              *reinterpret_cast<f16x4*>(dst) = hi;
+              *reinterpret_cast<f16x4*>(dst + 32) = lo;
+            } else {
+              *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
+            }
+          }
+        }
+    }
+    if (!more) break;
+    job = next;
+  }
+}
+
 __global__ void attention_merge_kernel(AttnP p) {
   // one thread per (batch, head, query, dim)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -766,7 +898,13 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
     p.qtiles = p.bpw == 2 ? 1 : (a->n1 + 31) / 32;
     const long njobs = (long)((a->nbatch + p.bpw - 1) / p.bpw) * p.qtiles;
     CtkProfScope ps(a->q_is == 1 ? "attention_time" : "attention_vself", flops, bytes, s);
-    if (p.bpw == 2) hipLaunchKernelGGL(attention_self_kernel<2>, dim3((unsigned)((njobs + 3) / 4), CTK_HEADS), dim3(256), 0, s, p);
+    const char* tk = getenv("CTK_ATTN_TIME");  // dev knob: 0 = the non-persistent kernel
+    if (p.bpw == 2 && !p.kmask && !p.qmask && !(tk && atoi(tk) == 0)) {
+      // persistent waves: 2 workgroups per CU, each wave walks over ~njobs*8/2048 (batch pair, head) jobs
+      const long total = njobs * CTK_HEADS;
+      const unsigned blocks = (unsigned)((total + 3) / 4 < 512 ? (total + 3) / 4 : 512);
+      hipLaunchKernelGGL(attention_time16_kernel, dim3(blocks), dim3(256), 0, s, p, total);
+    } else if (p.bpw == 2) hipLaunchKernelGGL(attention_self_kernel<2>, dim3((unsigned)((njobs + 3) / 4), CTK_HEADS), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attention_self_kernel<1>, dim3((unsigned)((njobs + 3) / 4), CTK_HEADS), dim3(256), 0, s, p);
     CTK_HIP_CHECK_LAUNCH();
     return CTK_OK;

@@ -347,7 +347,7 @@ class Window:
 
     def __init__(self, fmaps: Sequence[torch.Tensor], support: Sequence[torch.Tensor], coords: torch.Tensor,
                  vis: torch.Tensor, conf: torch.Tensor, scale_xy, iters: int = 6,
-                 point_mask: Optional[torch.Tensor] = None, max_corr_rows: int = 262144):
+                 point_mask: Optional[torch.Tensor] = None, max_corr_rows: int = 262144, use_aux_stream: bool = True):
         _chk_f32(*fmaps, *support, coords, vis, conf)
         S, N = coords.shape[0], coords.shape[1]
         assert coords.shape == (S, N, 2) and vis.shape == (S, N) and conf.shape == (S, N)
@@ -365,6 +365,7 @@ class Window:
         a.coords, a.vis, a.conf = _ptr(coords), _ptr(vis), _ptr(conf)
         a.scale_x, a.scale_y = float(scale_xy[0]), float(scale_xy[1])
         a.points_per_chunk = max(1, min(N, max_corr_rows // S))
+        a.aux_stream = aux_stream(coords.device).cuda_stream if use_aux_stream else None
         self.args = a
         self.S, self.N = S, N
         self.keep = (list(fmaps), list(support), coords, vis, conf, point_mask)
@@ -372,6 +373,17 @@ class Window:
 
 
 _ws_cache = {}
+_aux_streams = {}
+
+
+def aux_stream(device) -> torch.cuda.Stream:
+    """The per-device auxiliary stream handed to ctk_forward_window (ctk_window_args.aux_stream): the library forks
+    independent launches onto it and joins it back, so callers never synchronise with it themselves."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _aux_streams:
+        _aux_streams[key] = torch.cuda.Stream(device=device)
+    return _aux_streams[key]
+
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:

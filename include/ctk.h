@@ -122,6 +122,12 @@ typedef struct ctk_window_args {
   float* conf;                /* [S,N]   in/out, logits                                */
   float scale_x, scale_y;     /* model_resolution / stride = (W/4, H/4)  cotracker3_online.py:224-232 */
   int32_t points_per_chunk;   /* correlation stage processes this many points at a time (0 = all) */
+  void* aux_stream;           /* optional second HIP stream (or NULL).  When given, ctk_forward_window forks work onto it
+                                 and joins it back before returning control of `stream` to later launches: the sampler of
+                                 one point piece beside corr_mlp of the previous one, and the points<-virtual query
+                                 projection beside the virtual-track chain.  Same results, bit for bit (the launches and
+                                 their inputs are unchanged; only their stream differs).  Must not be the capture-origin
+                                 of another graph; safe inside ctk_window_graph_create (it joins that capture).  */
 } ctk_window_args;
 
 int ctk_abi_version(void);
