@@ -457,6 +457,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
   else gemm_epilogue_c<MR, NR, EPI>(g, acc, m0 + wm * 32 * MR, n0 + wn * 32 * NR, r32, half, bz);
 }
 
+// A persistent variant (resident workgroups walking over the tiles, the next tile's first two K-tiles prefetched by DMA
+// across the epilogue) was built and measured in round 2 and REMOVED: identical times (q/out shape 151.2 vs 152.4 us,
+// K >= 768 slightly slower; profiles/r02_gemm_persistent_ab.txt).  The per-tile cost that tools/bench_gemm_sweep.py
+// exposes (t = a + rounds * (T0 + KT * tk): T0 ~ 7 us, tk ~ 1.45 us against 0.73 us of MFMA issue) is therefore not
+// workgroup launch, prologue or a cold first DMA -- it is inside the tile: LDS traffic (64 KB of DMA writes + 128 KB of
+// fragment reads per K-tile and CU) needs about as many cycles as the 1536 MFMA cycles it feeds, and the two only
+// partly overlap at two waves per SIMD.
+
 // ---- weight packing ------------------------------------------------------------------------
 // hdr[0] = s = 2^(13 - floor(log2(max|W|))), hdr[1] = 1/s   (s = 1 for an all-zero matrix)
 __global__ __launch_bounds__(1024) void weight_scale_kernel(const float* W, long ldw, int N, int K, float* hdr) {
@@ -503,6 +511,7 @@ int gemm_tile_pref() {
   const char* e = getenv("CTK_GEMM_TILE");
   return e ? atoi(e) : 0;
 }
+
 template <typename K>
 int launch_with_lds(K kernel, unsigned blocks, unsigned threads, size_t lds_bytes, const CtkGemmP& g, hipStream_t s) {
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, s, g);
