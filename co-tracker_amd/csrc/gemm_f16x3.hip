@@ -537,7 +537,8 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
     // instead of three times and a wave issues 1.6 instead of 3.2 non-MFMA instructions per MFMA.  Opt-in only
     // (CTK_GEMM_TILE=4): for corr_mlp.fc1 it is 6 % faster in tools/bench_gemm.py (2.62 -> 2.47 ms) but slower inside
     // the update iteration (2.49 ms per launch, +25 ms per C3 step) -- one 8-wave block per CU starts cold behind
-    // the sampler where two 4-wave blocks overlap their prologues.
+    // the sampler where two 4-wave blocks overlap their prologues.  Round 2 re-measured it with compile-time epilogues
+    // for every N = 384 Linear (profiles/r02_gemm_fullrow_ab.txt): q/out -3...-9 %, fc2 -3...-9 %, C3 step +3.5 % slower.
     const long rows128 = (g.M + 127) / 128;
     const int code256 = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
     const bool epi256 = code256 == epi_code(CTK_ACT_NONE, false, false, false, true) ||      // to_kv
@@ -559,15 +560,20 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
         hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 4, 2, 2, epi_code(CTK_ACT_NONE, false, true, false, true)>), grid, blk, 0, s, g);
       else
         hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 4, 2, 2, EPI_GENERIC>), grid, blk, 0, s, g);
-    } else if (g.N == 384 && g.batch == 1 && pref == 4) {
+    } else if (g.N == 384 && g.batch == 1 && pref == 4 && rows128 >= 256) {
       g.mblocks = (int)rows128; g.nblocks = 1;
-      CtkProfScope ps("gemm_sh_128x384", flops, bytes, s);
+      CtkProfScope ps(prof_name("128x384"), flops, bytes, s);
       const int code = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
       const dim3 grid((unsigned)rows128), blk(512);
-      if (code == epi_code(CTK_ACT_GELU_ERF, false, true, false, true))
-        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 2, 3, 2, epi_code(CTK_ACT_GELU_ERF, false, true, false, true)>), grid, blk, 0, s, g);
-      else
-        hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 2, 3, 2, EPI_GENERIC>), grid, blk, 0, s, g);
+#define CTK_SH384(E) hipLaunchKernelGGL((gemm_sh_kernel<2, 4, 2, 3, 2, E>), grid, blk, 0, s, g)
+      switch (code) {
+        case epi_code(CTK_ACT_GELU_ERF, false, true, false, true): CTK_SH384(epi_code(CTK_ACT_GELU_ERF, false, true, false, true)); break;  // corr_mlp.fc1
+        case epi_code(CTK_ACT_NONE, false, false, true, false): CTK_SH384(epi_code(CTK_ACT_NONE, false, false, true, false)); break;        // input_transform
+        case epi_code(CTK_ACT_NONE, false, false, false, true): CTK_SH384(epi_code(CTK_ACT_NONE, false, false, false, true)); break;        // to_q
+        case epi_code(CTK_ACT_NONE, true, false, false, true): CTK_SH384(epi_code(CTK_ACT_NONE, true, false, false, true)); break;          // to_out / mlp.fc2
+        default: CTK_SH384(EPI_GENERIC);
+      }
+#undef CTK_SH384
     } else if (big && pref == 3) {
       g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 128;
       CtkProfScope ps("gemm_sh_256x128x3", flops, bytes, s);

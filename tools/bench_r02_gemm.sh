@@ -1,13 +1,16 @@
 #!/bin/bash
-# persistent-GEMM A/B: production shapes of one C3 iteration (tools/bench_gemm.py, SH in -> f32 / SH out) per knob setting
+# full-row (128 x 384, 8 waves) tile for the N = 384 Linears vs the default 128 x 128: production shapes + in situ
 mkdir -p gpurun_out
-for cfg in "0 0" "1 0" "2 0" "1 1"; do
-  set -- $cfg
-  echo "=== CTK_GEMM_PERSIST=$1 CTK_GEMM_TILE=$2"
-  CTK_GEMM_PERSIST=$1 CTK_GEMM_TILE=$2 MODES=sh,sh2sh ROUNDS=4 timeout 300 python tools/bench_gemm.py 2>&1 | grep -v amdgpu.ids
-done > gpurun_out/r02_gemm_persist_ab.txt 2>&1
-cat gpurun_out/r02_gemm_persist_ab.txt
-CTK_GEMM_PERSIST=1 timeout 200 python tools/bench_gemm_sweep.py 2>&1 | tail -30 > gpurun_out/r02_gemm_sweep_persist.txt
-tail -4 gpurun_out/r02_gemm_sweep_persist.txt
-# correctness of the persistent path on the GEMM / model tests
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "gemm or update_former or forward_window or full_size" 2>&1 | tail -5
+for t in 0 4; do
+  echo "=== CTK_GEMM_TILE=$t"
+  CTK_GEMM_TILE=$t MODES=sh ROUNDS=4 SHAPES=corr_fc1,in_proj,q_all,out_all,fc2_all,q_pts,out_pts,fc2_pts timeout 300 python tools/bench_gemm.py 2>&1 | grep -v amdgpu.ids
+done > gpurun_out/r02_gemm_fullrow_ab.txt 2>&1
+cat gpurun_out/r02_gemm_fullrow_ab.txt
+for t in 0 7 4; do
+  (CTK_GEMM_TILE=$t timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1) > gpurun_out/r02_var_tile$t.json
+  python - $t <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/r02_var_tile{sys.argv[1]}.json"))
+print("CTK_GEMM_TILE", sys.argv[1], d["value"], d["ms_per_step"], [(r["name"], r["avg_us"], r["total_ms"]) for r in d["kernels"] if "n384" in r["name"]])
+PY
+done
