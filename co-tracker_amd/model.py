@@ -378,6 +378,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         self.online_coords_predicted = None
         self.online_vis_predicted = None
         self.online_conf_predicted = None
+        self._online_batch = None  # B > 1: one state tuple per batch element (the attributes above hold the last one run)
 
     @torch.no_grad()
     def forward(self, video, queries, iters=4, is_train=False, add_space_attn=True, fmaps_chunk_size=200,
@@ -388,10 +389,22 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         if is_online:
             assert T <= S, "Online mode: video chunk must be <= window size."
             assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
-        if B != 1 and is_online:
-            raise NotImplementedError("online mode supports B=1")
-        outs = [self._guarded(lambda prec, b=b: self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, is_online, prec),
-                              self._online_snapshot() if is_online else None, self._online_restore) for b in range(B)]
+        run = lambda b: self._guarded(  # noqa: E731
+            lambda prec: self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, is_online, prec),
+            self._online_snapshot() if is_online else None, self._online_restore)
+        if is_online and B > 1:
+            # the reference carries the batch inside its state tensors; here every batch element owns a state tuple
+            # that is swapped in around its (independent) window
+            states = self._online_batch if self._online_batch is not None else [self._online_snapshot()] * B
+            assert len(states) == B, "batch size changed between online calls"
+            outs = []
+            for b in range(B):
+                self._online_restore(states[b])
+                outs.append(run(b))
+                states[b] = self._online_snapshot()
+            self._online_batch = states
+        else:
+            outs = [run(b) for b in range(B)]
         coords = torch.stack([o[0] for o in outs])
         vis = torch.stack([o[1] for o in outs])
         conf = torch.stack([o[2] for o in outs])

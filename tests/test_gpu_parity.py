@@ -570,6 +570,36 @@ def test_model_online_streaming_hip_graph(golden):
     assert maxdiff(logit(outs[True][1]), logit(g["on_stream_vis"])) < 1e-4
 
 
+def test_model_online_batched_streaming(golden):
+    """Online mode with B = 2 (the reference batches its online state tensors): each batch element keeps its own state,
+    so a batched stream equals the two single-video streams."""
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_online")
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=1)
+    m = m.to(dev())
+    v0, q0 = t(g["on_video"]), t(g["on_queries"])
+    v1 = v0.flip(1).contiguous()
+    q1 = q0.clone()
+    q1[..., 1] = 95.0 - q1[..., 1]
+    single = []
+    for v, q in ((v0, q0), (v1, q1)):
+        m.init_video_online_processing()
+        for ind in range(0, v.shape[1] - 4, 4):
+            out = m(v[:, ind:ind + 8], q, iters=4, is_online=True)
+        single.append(out)
+    m.init_video_online_processing()
+    vb, qb = torch.cat([v0, v1]), torch.cat([q0, q1])
+    for ind in range(0, vb.shape[1] - 4, 4):
+        cb, vbv, fb, _ = m(vb[:, ind:ind + 8], qb, iters=4, is_online=True)
+    assert cb.shape[0] == 2
+    for b in range(2):
+        assert maxdiff(cb[b], single[b][0][0]) < 3e-4            # MIOpen encoder run-to-run noise only
+        assert maxdiff(logit(vbv[b]), logit(single[b][1][0])) < 2e-4
+    assert maxdiff(cb[0], g["on_stream_coords"][0]) < 1e-3
+
+
 def test_model_offline(golden):
     from cotracker_amd.model import CoTrackerThreeOffline
     from cotracker_amd.weights import fill_synthetic_
