@@ -306,6 +306,20 @@ int ctk_gemm(const ctk_gemm_args* g, void* stream);
  * x = hi + lo (hi = rn16(x), lo = rn16(x - hi), |x| < 65504).  Same size as f32.  The split-half
  * GEMM streams it straight into LDS; LayerNorm / attention / GEMM epilogues / token assembly can
  * emit it.  ctk_split_rows converts f32 [M][K] (row stride ld floats) to SH.                      */
+/* Numeric range of the split-half format (what "fp32-class" means here; pinned by tests/test_gpu_range.py):
+ *   2^-3 <~ |x| < 65504   both halves are normal f16 numbers: x is carried with >= 21 significant bits, a product of two SH
+ *                          operands (3 MFMAs, f32 accumulate) has ~2^-21 relative error;
+ *   |x| <~ 2^-3            `lo` falls into the f16 subnormals (step 2^-24): the error becomes ABSOLUTE, <= 2^-25 per element;
+ *                          below 6.1e-5 `hi` is subnormal too -- same absolute bound.  Harmless where the consumer is on an
+ *                          absolute scale (softmax logits, residual adds on an O(1) stream), which is every consumer on this
+ *                          path: LayerNorm re-normalises the residual stream before every GEMM, and packed weights are
+ *                          pre-scaled by a power of two into [2^13, 2^14) so their own `lo` never underflows;
+ *   |x| >= 65504           `hi` overflows to inf, `lo` becomes -inf/NaN, and the non-finite value reaches the window state
+ *                          (coords / vis / conf) -- nothing on the path clamps or masks it.  The library itself does not test
+ *                          for it; the host models check the finished window state once per forward and re-run that forward on
+ *                          the exact-f32 back end (Wp == NULL everywhere) when it is non-finite (cotracker_amd/model.py,
+ *                          `range_guard`).  A caller that drives ctk_forward_window directly should do the same.
+ * The exact-f32 back end (v_mfma_f32_32x32x2_f32, f32 operands in HBM) has the reference's range and ~1/3 of the speed.    */
 int ctk_split_rows(const float* x, int64_t ld, int64_t M, int32_t K, void* out, void* stream);
 int ctk_pack_weight_bytes(int32_t N, int32_t K, size_t* out_bytes);
 int ctk_pack_weight(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream);
