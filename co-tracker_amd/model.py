@@ -290,11 +290,23 @@ class CoTrackerThreeBase(nn.Module):
             new.__dict__[k] = {} if k in ("_packed", "_graphs") else copy.deepcopy(v, memo)
         return new
 
-    def _guarded(self, run, snapshot=None, restore=None):
-        """run(precision) -> (coords, vis_logit, conf_logit) under the f16 range guard described in __init__."""
+    def _guarded(self, run, snapshot=None, restore=None, deferred=False):
+        """run(precision) -> (coords, vis_logit, conf_logit) under the f16 range guard described in __init__.
+        deferred=True (streaming): the finiteness flag of this call is copied to the host asynchronously and examined at
+        the START of the next call, so the stream of chunk calls never waits for the GPU; a hit then raises (the chunk
+        that overflowed has already been returned, and the online state is poisoned: the stream must be re-run with
+        ``precision="f32"``)."""
+        self._resolve_deferred_range_check()
         out = run(self.precision)
         if self.precision == "f16x3" and self.range_guard:
             finite = torch.stack([torch.isfinite(o).all() for o in out]).all()
+            if deferred:
+                flag = torch.empty((), dtype=torch.bool, pin_memory=True)
+                flag.copy_(finite, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_range = (flag, ev)
+                return out
             if not bool(finite):
                 self.range_fallbacks += 1
                 warnings.warn("cotracker_amd: non-finite tracks from the split-half (f16x3) back end -- an activation left "
@@ -304,6 +316,17 @@ class CoTrackerThreeBase(nn.Module):
                     restore(snapshot)
                 out = run("f32")
         return out
+
+    def _resolve_deferred_range_check(self):
+        pending, self._pending_range = getattr(self, "_pending_range", None), None
+        if pending is not None:
+            flag, ev = pending
+            ev.synchronize()
+            if not bool(flag):
+                self.range_fallbacks += 1
+                raise FloatingPointError("cotracker_amd: the previous streaming chunk produced non-finite tracks on the "
+                                         "split-half (f16x3) back end (an activation left the f16 range |x| < 65504, or the "
+                                         "input was non-finite); restart the stream with model.precision = 'f32'")
 
     def _graphed_window(self, fm, support, coords, vis, conf, mask, iters, pw):
         """Run one window through its captured hipGraph: static buffers are created (and the graph captured) on
@@ -378,6 +401,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         self.online_coords_predicted = None
         self.online_vis_predicted = None
         self.online_conf_predicted = None
+        self._pending_range = None
         self._online_batch = None  # B > 1: one state tuple per batch element (the attributes above hold the last one run)
 
     @torch.no_grad()
@@ -389,9 +413,11 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         if is_online:
             assert T <= S, "Online mode: video chunk must be <= window size."
             assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
+        # streaming with the window graph (CoTrackerOnlinePredictor): deferred range check, the chunk stream stays asynchronous
+        deferred = bool(is_online and self.hip_graph and B == 1)
         run = lambda b: self._guarded(  # noqa: E731
             lambda prec: self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, is_online, prec),
-            self._online_snapshot() if is_online else None, self._online_restore)
+            self._online_snapshot() if is_online else None, self._online_restore, deferred)
         if is_online and B > 1:
             # the reference carries the batch inside its state tensors; here every batch element owns a state tuple
             # that is swapped in around its (independent) window

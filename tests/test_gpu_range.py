@@ -174,8 +174,16 @@ def test_overflow_gives_defined_result_not_nan():
     m.range_guard = False
     c_raw, *_ = m(video, q, iters=3)
     assert not torch.isfinite(c_raw).all()
-    # streaming: the online state is restored before the f32 re-run
+    # streaming through the window graph (CoTrackerOnlinePredictor's mode): the check is deferred by one call so the
+    # chunk stream never waits for the GPU -- the NEXT call raises a defined error instead of handing on NaN state
     m.range_guard = True
+    m.hip_graph = True
+    m.init_video_online_processing()
+    m(video[:, 0:8], q, iters=2, is_online=True)
+    with pytest.raises(FloatingPointError, match="f16 range"):
+        m(video[:, 4:12], q, iters=2, is_online=True)
+    m.hip_graph = False
+    # streaming without the graph: immediate check, the online state is restored before the f32 re-run
     m.init_video_online_processing()
     exact.init_video_online_processing()
     for ind in range(0, 8, 4):
