@@ -187,6 +187,17 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
     for (int pl = 0; pl < 2; ++pl) coff[s][pl] = ((pl * 4 + s * 2 + half) ^ fsw) << 4;
   const int ctile = wave & 1, rtile = wave >> 1;
   const unsigned char* sup_frag = sup + (ctile * 32 + r32) * 128;
+  // The support patch does not change over the chunk's frames: this wave's B fragments (its 32 tap columns, all four
+  // K-tiles, hi and lo) are read from LDS ONCE and stay in 64 VGPRs instead of 16 of the 61 ds_read_b128 a wave issued
+  // per frame (248 VGPRs, no spill; round 2: 2.78 -> 2.73 ms per launch at C3, same bits).
+  f16x8 bh[NKT][2], bl[NKT][2];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bh[kt][s] = *reinterpret_cast<const f16x8*>(sup_frag + kt * SUP_KT + coff[s][0]);
+      bl[kt][s] = *reinterpret_cast<const f16x8*>(sup_frag + kt * SUP_KT + coff[s][1]);
+    }
 
   // blend role of this thread: tap p = tid / 5, q chunk (tid % 5) * 12 (12 values; the last chunk holds q = 48 only)
   const int bp = tid / 5, bq0 = (tid - bp * 5) * 12;
@@ -210,15 +221,13 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
       f32x16 acc_b;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acc_b[e] = 0.0f; }
-      f16x8 ah[NKT][2], al[NKT][2], bh[NKT][2], bl[NKT][2];
+      f16x8 ah[NKT][2], al[NKT][2];
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           ah[kt][s] = *reinterpret_cast<const f16x8*>(arow + kt * (FROWS * 128) + coff[s][0]);
           al[kt][s] = *reinterpret_cast<const f16x8*>(arow + kt * (FROWS * 128) + coff[s][1]);
-          bh[kt][s] = *reinterpret_cast<const f16x8*>(sup_frag + kt * SUP_KT + coff[s][0]);
-          bl[kt][s] = *reinterpret_cast<const f16x8*>(sup_frag + kt * SUP_KT + coff[s][1]);
         }
       // A = pixels (rows i), B = support taps (columns j): D[i][j], lane holds column j = lane & 31
 #pragma unroll

@@ -57,6 +57,20 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ctk_window_graph_destroy(None) == 0
 
 
+def test_v2_driver_argument_validation_without_gpu(lib):
+    """ctk_forward_window_v2 / ctk_v2_window_graph_create reject bad arguments before touching the device."""
+    from cotracker_amd import _lib as L
+    a, w, n = L.V2WindowArgs(), L.V2Weights(), C.c_size_t(0)
+    assert lib.ctk_forward_window_v2_workspace_bytes(None, None, C.byref(n)) == -1
+    a.S, a.N, a.iters = 8, 10, 4
+    assert lib.ctk_forward_window_v2_workspace_bytes(C.byref(a), C.byref(w), C.byref(n)) == -2   # former dims unset
+    w.former.in_dim, w.former.in_ld, w.former.out_dim, w.former.out_ld = 456, 480, 130, 192
+    assert lib.ctk_forward_window_v2_workspace_bytes(C.byref(a), C.byref(w), C.byref(n)) == -1   # NULL tensors
+    assert lib.ctk_forward_window_v2(C.byref(a), C.byref(w), None, 0, None) == -1
+    h = C.c_void_p()
+    assert lib.ctk_v2_window_graph_create(C.byref(a), C.byref(w), None, 0, C.byref(h)) == -1 and not h.value
+
+
 def test_struct_sizes_match_header(tmp_path):
     """ctypes mirrors vs the C compiler's view of include/ctk.h: sizeof of every struct that crosses the boundary."""
     import subprocess
