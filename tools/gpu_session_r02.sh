@@ -69,3 +69,17 @@ if has pmc; then
   find gpurun_out/prof_fetch gpurun_out/prof_write -name '*.csv' -size +20M -delete
   du -sh gpurun_out
 fi
+if has sq; then
+  # SQ counters per kernel (MFMA-pipe utilisation, issue / wait split) and an LDS pass, one bench step each
+  R=$GRAFT_REPO_ROOT
+  cd /tmp
+  CMD0="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile"
+  (cd $R && timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/prof_sq -- $CMD0 > $R/gpurun_out/prof_sq.log 2>&1)
+  (cd $R && timeout 900 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/prof_lds -- $CMD0 > $R/gpurun_out/prof_lds.log 2>&1)
+  cd $R
+  F=$(ls -t $(find gpurun_out/prof_sq -name "*counter_collection.csv") | head -1)
+  python tools/summarize_sq.py "$F" "" gpurun_out/r02_sq_counters.txt | cut -c1-260
+  F=$(ls -t $(find gpurun_out/prof_lds -name "*counter_collection.csv") | head -1)
+  python tools/summarize_lds.py "$F" gpurun_out/r02_lds_counters.txt | cut -c1-220
+  find gpurun_out/prof_sq gpurun_out/prof_lds -name '*.csv' -size +20M -delete
+fi
