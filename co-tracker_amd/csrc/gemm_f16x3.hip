@@ -461,9 +461,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
 // across the epilogue) was built and measured in round 2 and REMOVED: identical times (q/out shape 151.2 vs 152.4 us,
 // K >= 768 slightly slower; profiles/r02_gemm_persistent_ab.txt).  The per-tile cost that tools/bench_gemm_sweep.py
 // exposes (t = a + rounds * (T0 + KT * tk): T0 ~ 7 us, tk ~ 1.45 us against 0.73 us of MFMA issue) is therefore not
-// workgroup launch, prologue or a cold first DMA -- it is inside the tile: LDS traffic (64 KB of DMA writes + 128 KB of
-// fragment reads per K-tile and CU) needs about as many cycles as the 1536 MFMA cycles it feeds, and the two only
-// partly overlap at two waves per SIMD.
+// workgroup launch, prologue or a cold first DMA -- it is inside the tile.  SQ counters (profiles/r02_sq_counters.txt,
+// r02_lds_counters.txt): waves are issuing 16 % of their lifetime and sit in s_waitcnt 61 % of it; the LDS array is only
+// ~13 % busy with fragment reads (no conflicts), the MFMA pipe ~40 %: latency-bound at two waves per SIMD, not LDS-bound.
 
 // ---- weight packing ------------------------------------------------------------------------
 // hdr[0] = s = 2^(13 - floor(log2(max|W|))), hdr[1] = 1/s   (s = 1 for an all-zero matrix)
