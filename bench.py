@@ -117,9 +117,13 @@ def cpu_baseline(workload):
             f = os.path.join(ROOT, "tests", "golden", f"scale_{name}.npz")
             if os.path.exists(f):
                 g = np.load(f)
-                n, t = g["coords"].shape[1], g["coords"].shape[0]
-                ref[name] = {"tracked_point_frames_per_s": round(n * t / float(g["seconds"]), 1), "threads": int(g["threads"]),
-                             "host_cpus": int(g["host_cpus"]), "seconds": round(float(g["seconds"]), 1)}
+                n, t = int(g["n_points_total"]) if "n_points_total" in g else g["coords"].shape[1], g["coords"].shape[0]
+                # two runs per golden (different intra-op thread counts); report the faster: the slower one may have
+                # shared the container with other jobs
+                runs = [(float(g["seconds"]), int(g["threads"])), (float(g["noise_seconds"]), int(g["noise_threads"]))]
+                sec, thr = min(runs)
+                ref[name] = {"tracked_point_frames_per_s": round(n * t / sec, 1), "threads": thr, "host_cpus": int(g["host_cpus"]),
+                             "seconds": round(sec, 1), "points": n, "frames": t}
         res["reference_in_build_container"] = ref
     except Exception:
         pass

@@ -889,7 +889,7 @@ def test_cotracker2_damped_heads_four_iterations(golden, precision):
         assert maxdiff(cs, g["stream_coords"]) < tol_cs
         assert maxdiff(logit(vs), logit(g["stream_vis"])) < tol_v
         assert bool(m._graphs) == use_graph
-    assert next(iter(m._graphs.values())).nodes > 1000  # 4 iterations x ~390 launches in ONE graph
+    assert next(iter(m._graphs.values())).nodes > 500  # 4 iterations x ~210 launches (6 + 6 layers) in ONE graph
 
 
 def test_cotracker2_window_graph_replay_is_bit_identical(golden, precision):

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 WHAT="${*:-tests bench}"
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 if has tests; then
-  (timeout 1500 python -m pytest tests -m gpu -q -x --durations=8 2>&1 | tail -60) > gpurun_out/r02_pytest_gpu.log
+  (timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -60) > gpurun_out/r02_pytest_gpu.log
   tail -25 gpurun_out/r02_pytest_gpu.log
 fi
 if has bench; then
