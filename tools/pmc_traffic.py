@@ -16,6 +16,17 @@ import re
 import sys
 
 NAME_MAP = [
+    # the compile-time epilogue code (last template argument) identifies the Linear where it is unique, which lets the
+    # per-shape recorder rows of bench.py (gemm_sh_<tile>_k<K>_n<N>) pick up their own traffic:
+    #   256x256: 42 = mlp.fc1 (tanh-GELU, SH out), 32 = to_kv (bias only), 40 = corr_mlp.fc2 (SH out)
+    #   128x128: 41 = corr_mlp.fc1 (erf-GELU, SH out), 16 = input_transform (bias rows), 32 = to_q; 36 = to_out AND mlp.fc2
+    (r"gemm_sh_kernel<2, 4, 4, 2, 2, 42>", "gemm_sh_256_k384_n1536"),
+    (r"gemm_sh_kernel<2, 4, 4, 2, 2, 32>", "gemm_sh_256_k384_n768"),
+    (r"gemm_sh_kernel<2, 4, 4, 2, 2, 40>", "gemm_sh_256_k384_n256"),
+    (r"gemm_sh_kernel<2, 2, 2, 2, 2, 41>", "gemm_sh_128_k2432_n384"),
+    (r"gemm_sh_kernel<2, 2, 2, 2, 2, 16>", "gemm_sh_128_k1120_n384"),
+    (r"gemm_sh_kernel<2, 2, 2, 2, 2, 32>", "gemm_sh_128_to_q"),
+    (r"gemm_sh_kernel<2, 2, 2, 2, 2, 36>", "gemm_sh_128_to_out_and_fc2"),
     (r"gemm_sh_kernel<2, 4, 2, 3,", "gemm_sh_128x384"),
     (r"gemm_sh_kernel<2, 4, 4, 2,", "gemm_sh_256x256"),
     (r"gemm_sh_kernel<2, 2, 2, 2,", "gemm_sh_128x128"),
@@ -29,6 +40,7 @@ NAME_MAP = [
     (r"corr_volume_sh_kernel", "corr_volume_sh"),
     (r"corr_volume_kernel", "corr_volume"),
     (r"attention_merge_kernel", "attention_merge"),
+    (r"attention_time16_kernel", "attention_time"),
     (r"attention_self_kernel", "attention_time"),
     (r"attention_kv64_kernel", "attention_p2v"),   # also the (small) virtual self attention launches
     (r"attention_q64_kernel", "attention_v2p"),
