@@ -202,7 +202,13 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
   // blend role of this thread: tap p = tid / 5, q chunk (tid % 5) * 12 (12 values; the last chunk holds q = 48 only)
   const int bp = tid / 5, bq0 = (tid - bp * 5) * 12;
   const int bcnt = (tid < 245) ? (bq0 < 48 ? 12 : 1) : 0;
-  const int bhx = bp / 7, bwy = bp - bhx * 7;  // first 7-index = x offset, second = y (cotracker3_online.py:102-104)
+  // Threads are dealt to taps X-FASTEST (bp -> y = bp / 7, x = bp % 7): the corner pixels of neighbouring threads are then
+  // neighbouring C rows (68 floats apart = 1 slot of the 16 four-bank slots a ds_read_b128 group can use) instead of rows
+  // fw = 8 pixels apart (544 floats = 8 slots: taps k and k + 2 of a 16-lane group collided, a 2-way bank conflict on
+  // all 12 reads).  The OUTPUT column of the tap is unchanged: p = x * 7 + y, first 7-index = x offset
+  // (cotracker3_online.py:102-104).
+  const int bwy = bp / 7, bhx = bp - bwy * 7;
+  const int bpo = bhx * 7 + bwy;  // the tap's column block in the volume row
 
   for (int tl = 0; tl < nt; ++tl) {
     const FrameTab* tab = tabs + tl;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
       const float* c10 = C + (y0 * fw + x1) * CPITCH + bq0;
       const float* c01 = C + (y1 * fw + x0) * CPITCH + bq0;
       const float* c11 = C + (y1 * fw + x1) * CPITCH + bq0;
-      float* dst = stg + bp * CTK_TAPS + bq0;
+      float* dst = stg + bpo * CTK_TAPS + bq0;
       if (bcnt == 12) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
