@@ -242,6 +242,8 @@ class CoTrackerThreeBase(nn.Module):
         self.range_guard = True
         self.range_fallbacks = 0
         self.encoder_dtype = torch.float32  # fp32 as the reference; see tools/probe_encoder_precision.py for why not lower
+        # streaming: reuse the previous chunk's features for the overlapping frames (see _encode_online); not a reference kwarg
+        self.online_feature_cache = True
         # pre-sigmoid (visibility, confidence) of the last forward, [B,T,N] each -- parity tests compare logits
         self.last_logits = None
 
@@ -318,6 +320,15 @@ class CoTrackerThreeBase(nn.Module):
         return out
 
     def _resolve_deferred_range_check(self):
+        pending, self._pending_overlap = getattr(self, "_pending_overlap", None), None
+        if pending is not None:
+            flag, ev = pending
+            ev.synchronize()
+            if bool(flag):
+                raise ValueError("cotracker_amd: online chunks must overlap -- the first window_len - step frames of a chunk "
+                                 "have to be the last frames of the previous chunk (predictor.py:225,288-290); the cached "
+                                 "features of the previous call were used for them.  Set model.online_feature_cache = False "
+                                 "to re-encode every chunk in full as the reference does.")
         pending, self._pending_range = getattr(self, "_pending_range", None), None
         if pending is not None:
             flag, ev = pending
@@ -401,6 +412,9 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         self.online_coords_predicted = None
         self.online_vis_predicted = None
         self.online_conf_predicted = None
+        self.online_f0_tail = None        # level-0 features of the frames the NEXT chunk starts with (feature cache)
+        self._online_prev_frames = None   # those frames themselves, to verify the overlap asynchronously
+        self._pending_overlap = None
         self._pending_range = None
         self._online_batch = None  # B > 1: one state tuple per batch element (the attributes above hold the last one run)
 
@@ -439,13 +453,39 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
 
     def _online_snapshot(self):
         return (self.online_ind, list(self.online_track_support), self.online_coords_predicted, self.online_vis_predicted,
-                self.online_conf_predicted)
+                self.online_conf_predicted, self.online_f0_tail, self._online_prev_frames)
 
     def _online_restore(self, snap):
         if snap is not None:
             (self.online_ind, sup, self.online_coords_predicted, self.online_vis_predicted,
-             self.online_conf_predicted) = snap
+             self.online_conf_predicted, self.online_f0_tail, self._online_prev_frames) = snap
             self.online_track_support = list(sup)
+
+    def _encode_online(self, video, chunk, S, step):
+        """Streaming: consecutive chunks overlap by S - step frames (predictor.py:225,288-290 feeds the last 2*step frames
+        every step), and the encoder is per-frame, so the overlapping frames' level-0 features are the ones computed one
+        call ago.  With ``online_feature_cache`` only the `step` NEW frames go through the CNN (half the encoder time of a
+        streaming call).  That the overlapping frames really are the previous chunk's is verified on the device and
+        checked one call later (no host synchronisation in the stream); a mismatch raises."""
+        T = video.shape[0]
+        ov = S - step
+        tail, prev = self.online_f0_tail, self._online_prev_frames
+        if self.online_feature_cache and T == S and tail is not None and tail.shape[0] == ov and prev.shape == video[:ov].shape:
+            bad = (video[:ov] != prev).any()
+            flag = torch.empty((), dtype=torch.bool, pin_memory=True)
+            flag.copy_(bad, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending_overlap = (flag, ev)
+            f0 = torch.cat([tail, self._encode(video[ov:].float(), chunk)], dim=0)
+        else:
+            f0 = self._encode(video.float(), chunk)
+        if self.online_feature_cache and T == S:
+            self.online_f0_tail = f0[step:]
+            self._online_prev_frames = video[step:].clone()
+        else:
+            self.online_f0_tail = self._online_prev_frames = None
+        return f0
 
     def _forward_one(self, video, queries, iters, chunk, is_online, precision=None):
         T = video.shape[0]
@@ -461,7 +501,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         # encoder + pyramid.  The reference pads the *video* by repeating its last frame
         # (:321-328); the encoder is per-frame, so repeating the last feature map is identical.
         pad = (S - T) if is_online else (S - T % S) % S
-        f0 = self._encode(video.float(), chunk)
+        f0 = self._encode_online(video, chunk, S, step) if is_online else self._encode(video.float(), chunk)
         if pad > 0:
             f0 = torch.cat([f0, f0[-1:].expand(pad, -1, -1, -1)], dim=0).contiguous()
         pyr = ops.build_pyramid(f0, self.corr_levels)

@@ -570,6 +570,36 @@ def test_model_online_streaming_hip_graph(golden):
     assert maxdiff(logit(outs[True][1]), logit(g["on_stream_vis"])) < 1e-4
 
 
+def test_model_online_feature_cache(golden):
+    """Streaming re-uses the previous chunk's level-0 features for the overlapping frames (only the `step` new frames go
+    through the CNN): same tracks as re-encoding every chunk in full, and as the reference golden; chunks that do NOT
+    overlap are detected (one call later, without a host sync in the stream) and raise."""
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_online")
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=1)
+    m = m.to(dev())
+    video, q = t(g["on_video"]), t(g["on_queries"])
+    outs = {}
+    for cache in (True, False):
+        m.online_feature_cache = cache
+        m.init_video_online_processing()
+        for ind in range(0, video.shape[1] - 4, 4):
+            cs, vs, fs, _ = m(video[:, ind:ind + 8], q, iters=4, is_online=True)
+        outs[cache] = (cs.clone(), vs.clone())
+        assert (m.online_f0_tail is not None) == cache
+    assert maxdiff(outs[True][0], outs[False][0]) < 3e-4   # the encoder sees 4 instead of 8 frames per call: rounding only
+    assert maxdiff(outs[True][0], g["on_stream_coords"]) < 1e-3
+    assert maxdiff(logit(outs[True][1]), logit(g["on_stream_vis"])) < 1e-4
+    m.online_feature_cache = True
+    m.init_video_online_processing()
+    m(video[:, 0:8], q, iters=1, is_online=True)
+    m(video[:, 8:16], q, iters=1, is_online=True)          # NOT the overlapping chunk video[:, 4:12]
+    with pytest.raises(ValueError, match="must overlap"):
+        m(video[:, 8:16], q, iters=1, is_online=True)
+
+
 def test_model_online_batched_streaming(golden):
     """Online mode with B = 2 (the reference batches its online state tensors): each batch element keeps its own state,
     so a batched stream equals the two single-video streams."""
