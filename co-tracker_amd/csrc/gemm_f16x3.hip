@@ -530,7 +530,9 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
   };
 
   const long blocks128 = (long)((g.M + 127) / 128) * (g.N / 128) * g.batch;
-  const bool big = (g.N % 128) == 0 && blocks128 >= 384;
+  // 128 x 128 tiles once they fill most of the 512 resident slots, 64 x 64 below (CTK_GEMM_BIG_MIN overrides the threshold)
+  static const long big_min = [] { const char* e = getenv("CTK_GEMM_BIG_MIN"); return e ? atol(e) : 384L; }();
+  const bool big = (g.N % 128) == 0 && blocks128 >= big_min;
   if (g.a_split) {
     const int pref = gemm_tile_pref();
     // 128x384 tile (8 waves as 2 x 4, each 64 x 96): the block owns full rows of an N = 384 Linear, A is fetched once
