@@ -576,6 +576,37 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
         default: CTK_SH384(EPI_GENERIC);
       }
 #undef CTK_SH384
+    } else if (g.N == 384 && g.batch == 1 && (pref == 8 || pref == 9) && rows128 >= 256) {
+      // Round-2 experiments, ONE wave per SIMD (4 waves, one workgroup per CU, up to 512 registers per wave):
+      //   8: 128 x 384 tile, waves 1 x 4, wave tile 128 x 96 (36 MFMAs per 14 fragment reads), 2 LDS stages of 64 KB
+      //   9: 256 x 128 tile, waves 2 x 2, wave tile 128 x 64 (24 MFMAs per 12 reads), 3 LDS stages of 48 KB, counted vmcnt
+      const int code = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
+      const dim3 blk(256);
+      if (pref == 8) {
+        g.mblocks = (int)rows128; g.nblocks = 1;
+        CtkProfScope ps(prof_name("w128x384"), flops, bytes, s);
+        const dim3 grid((unsigned)rows128);
+#define CTK_SHW(E) hipLaunchKernelGGL((gemm_sh_kernel<1, 4, 4, 3, 2, E>), grid, blk, 0, s, g)
+        switch (code) {
+          case epi_code(CTK_ACT_GELU_ERF, false, true, false, true): CTK_SHW(epi_code(CTK_ACT_GELU_ERF, false, true, false, true)); break;
+          case epi_code(CTK_ACT_NONE, false, false, false, true): CTK_SHW(epi_code(CTK_ACT_NONE, false, false, false, true)); break;
+          case epi_code(CTK_ACT_NONE, true, false, false, true): CTK_SHW(epi_code(CTK_ACT_NONE, true, false, false, true)); break;
+          default: CTK_SHW(EPI_GENERIC);
+        }
+#undef CTK_SHW
+      } else {
+        g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 128;
+        CtkProfScope ps(prof_name("w256x128x3"), flops, bytes, s);
+        const dim3 grid((unsigned)((long)g.mblocks * g.nblocks));
+#define CTK_SHW(E) hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 4, 2, 3, E>), grid, blk, 0, s, g)
+        switch (code) {
+          case epi_code(CTK_ACT_GELU_ERF, false, true, false, true): CTK_SHW(epi_code(CTK_ACT_GELU_ERF, false, true, false, true)); break;
+          case epi_code(CTK_ACT_NONE, false, false, false, true): CTK_SHW(epi_code(CTK_ACT_NONE, false, false, false, true)); break;
+          case epi_code(CTK_ACT_NONE, true, false, false, true): CTK_SHW(epi_code(CTK_ACT_NONE, true, false, false, true)); break;
+          default: CTK_SHW(EPI_GENERIC);
+        }
+#undef CTK_SHW
+      }
     } else if (big && pref == 3) {
       g.mblocks = (g.M + 255) / 256; g.nblocks = g.N / 128;
       CtkProfScope ps("gemm_sh_256x128x3", flops, bytes, s);
