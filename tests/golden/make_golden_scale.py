@@ -41,6 +41,11 @@ CONFIGS = {
     "c4": (512, 512, 48, 32, "online", 16, 8, 3),
     "c3_g40": (512, 512, 120, 40, "sliding", 16, 8, 3),
     "c3_g80": (512, 512, 120, 80, "sliding", 16, 8, 5),
+    # explicit queries at RANDOM frames (grid = sqrt of the point count): exercises, at the real resolution, the paths the
+    # frame-0 grids never touch -- support masked until a track's query frame enters the window, per-window carry-over of
+    # only the already-queried tracks, the 6x6 support grid the predictor appends, backward tracking (a second, time-flipped
+    # model pass merged for the frames before each query)
+    "c3_q": (512, 512, 64, 32, "queries", 16, 8, 3),
 }
 
 
@@ -73,7 +78,7 @@ def run(name, threads):
     if kind == "online":
         p = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
     else:
-        p = CoTrackerPredictor(checkpoint=None, offline=(kind == "offline"), window_len=wl)
+        p = CoTrackerPredictor(checkpoint=None, offline=(kind == "offline"), window_len=wl)  # "sliding" / "queries": online weights
     fill_synthetic_(p.model, seed=0)
     model_forward = p.model.forward
 
@@ -85,14 +90,22 @@ def run(name, threads):
     p.model.forward = tap_forward
     t0 = time.time()
     with SigmoidTap() as tap:
-        if kind == "online":
+        if kind == "queries":
+            g = torch.Generator().manual_seed(77)
+            n = G * G
+            q = torch.stack([torch.randint(0, T - 8, (n,), generator=g).float(), torch.rand(n, generator=g) * (W - 1),
+                             torch.rand(n, generator=g) * (H - 1)], dim=1)[None]
+            q[0, : n // 4, 0] = 0
+            tracks, vis = p(video, queries=q, backward_tracking=True)
+            captured["coords"] = tracks  # two model passes are merged: the predictor-level tracks are the comparable output
+        elif kind == "online":
             p(video_chunk=video[:, :2 * p.step], is_first_step=True, grid_size=G)
             for ind in range(0, T - p.step, p.step):
                 tracks, vis = p(video_chunk=video[:, ind: ind + 2 * p.step])
         else:
             tracks, vis = p(video, grid_size=G)
     dt = time.time() - t0
-    vis_logit, conf_logit = tap.args[-2], tap.args[-1]  # the last two sigmoid calls are the returned vis / conf
+    vis_logit, conf_logit = tap.args[-2], tap.args[-1]  # the last two sigmoid calls are the returned vis / conf (queries: of the backward pass)
     out = dict(coords=captured["coords"][0], vis_logit=vis_logit[0].reshape(vis_logit.shape[1], -1),
                conf_logit=conf_logit[0].reshape(conf_logit.shape[1], -1), tracks=tracks[0], vis=vis[0])
     out = {k: v.cpu().numpy() for k, v in out.items()}
