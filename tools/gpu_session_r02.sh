@@ -39,7 +39,7 @@ PY
 fi
 if has dist; then
   # the multi-rank code path on a 1-GPU box: 2 ranks over gloo, both on cuda:0 (numbers meaningless, path exercised)
-  (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 1 --warmup 1 --workload tiny --dist-backend gloo --single-device --no-profile 2>gpurun_out/r02_bench_2rank.err | tail -1) > gpurun_out/r02_bench_2rank_gloo.json
+  (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 1 --warmup 1 --workload tiny --dist-backend gloo --single-device 2>gpurun_out/r02_bench_2rank.err | tail -1) > gpurun_out/r02_bench_2rank_gloo.json
   (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 1 --warmup 1 --workload c5_shard --dist-backend gloo --single-device --no-profile 2>>gpurun_out/r02_bench_2rank.err | tail -1) > gpurun_out/r02_bench_2rank_c5_gloo.json
   head -c 600 gpurun_out/r02_bench_2rank_gloo.json; echo; head -c 600 gpurun_out/r02_bench_2rank_c5_gloo.json; echo; tail -3 gpurun_out/r02_bench_2rank.err
 fi
