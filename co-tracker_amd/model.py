@@ -244,6 +244,7 @@ class CoTrackerThreeBase(nn.Module):
         self.encoder_dtype = torch.float32  # fp32 as the reference; see tools/probe_encoder_precision.py for why not lower
         # streaming: reuse the previous chunk's features for the overlapping frames (see _encode_online); not a reference kwarg
         self.online_feature_cache = True
+        self.encoder_chunk = 16  # frames per CNN call (see _encode); not a reference kwarg
         # pre-sigmoid (visibility, confidence) of the last forward, [B,T,N] each -- parity tests compare logits
         self.last_logits = None
 
@@ -372,17 +373,23 @@ class CoTrackerThreeBase(nn.Module):
         return (self.model_resolution[1] / self.stride, self.model_resolution[0] / self.stride)
 
     def _encode(self, frames: torch.Tensor, chunk: int) -> torch.Tensor:
-        """frames [T,3,H,W] in 0..255 -> L2-normalised NHWC level-0 features [T,H/4,W/4,128]."""
-        outs = []
-        for t0 in range(0, frames.shape[0], chunk):
-            x = 2 * (frames[t0:t0 + chunk] / 255.0) - 1.0  # cotracker3_online.py:320
+        """frames [T,3,H,W] in 0..255 -> L2-normalised NHWC level-0 features [T,H/4,W/4,128].
+        The CNN is per-frame, so the frames go through it `encoder_chunk` at a time whatever `fmaps_chunk_size` the caller
+        asked for: 16 frames keep the layer activations (150 MB at 384x512) inside the 256 MB Infinity Cache, which is as
+        fast as or faster than one 120-frame batch (100 vs 102-130 ms, tools/bench_encoder_chunk.py) at a tenth of the
+        memory; every chunk is normalised straight into its frame range of the output."""
+        T, _, H, W = frames.shape
+        step = max(1, min(int(chunk), int(self.encoder_chunk)))
+        out = torch.empty(T, H // self.stride, W // self.stride, self.latent_dim, device=frames.device, dtype=torch.float32)
+        for t0 in range(0, T, step):
+            x = 2 * (frames[t0:t0 + step] / 255.0) - 1.0  # cotracker3_online.py:320
             if self.encoder_dtype == torch.float32:
                 f = self.fnet(x)
             else:  # experiment knob (tools/probe_encoder_precision.py): MIOpen convolutions in half precision
                 with torch.autocast("cuda", dtype=self.encoder_dtype):
                     f = self.fnet(x)
-            outs.append(ops.normalize_to_nhwc(f.float().contiguous()))
-        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+            ops.normalize_to_nhwc(f.float().contiguous(), out=out[t0:t0 + step])
+        return out
 
     def _support(self, pyr, frames_f: torch.Tensor, qcoords: torch.Tensor):
         return [ops.sample_support(pyr[l], frames_f, (qcoords / 2 ** l).contiguous()) for l in range(self.corr_levels)]

@@ -135,12 +135,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, splits: int = 1
 # ------------------------------------------------------------------------------------------
 # pyramid / samplers
 # ------------------------------------------------------------------------------------------
-def normalize_to_nhwc(fmaps_nchw: torch.Tensor) -> torch.Tensor:
-    """[F,128,H,W] -> channel-L2-normalised NHWC [F,H,W,128] (cotracker3_online.py:384-394)."""
+def normalize_to_nhwc(fmaps_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[F,128,H,W] -> channel-L2-normalised NHWC [F,H,W,128] (cotracker3_online.py:384-394); `out` = a contiguous
+    [F,H,W,128] destination (e.g. a frame range of a preallocated feature tensor)."""
     _chk_f32(fmaps_nchw)
     F_, Cc, H, W = fmaps_nchw.shape
     assert Cc == 128
-    out = torch.empty(F_, H, W, Cc, device=fmaps_nchw.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(F_, H, W, Cc, device=fmaps_nchw.device, dtype=torch.float32)
+    else:
+        _chk_f32(out)
+        assert out.shape == (F_, H, W, Cc)
     L.check(L.load().ctk_normalize_to_nhwc(_ptr(fmaps_nchw), F_, H, W, _ptr(out), _stream()), "ctk_normalize_to_nhwc")
     return out
 
