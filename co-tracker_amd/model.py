@@ -375,9 +375,10 @@ class CoTrackerThreeBase(nn.Module):
     def _encode(self, frames: torch.Tensor, chunk: int) -> torch.Tensor:
         """frames [T,3,H,W] in 0..255 -> L2-normalised NHWC level-0 features [T,H/4,W/4,128].
         The CNN is per-frame, so the frames go through it `encoder_chunk` at a time whatever `fmaps_chunk_size` the caller
-        asked for: 16 frames keep the layer activations (150 MB at 384x512) inside the 256 MB Infinity Cache, which is as
-        fast as or faster than one 120-frame batch (100 vs 102-130 ms, tools/bench_encoder_chunk.py) at a tenth of the
-        memory; every chunk is normalised straight into its frame range of the output."""
+        asked for: 16 frames keep the layer activations (150 MB at 384x512) inside the 256 MB Infinity Cache -- the same
+        speed as one 120-frame batch in situ (C3 step 1 521 vs 1 517-1 533 ms; 100 vs 102-130 ms in
+        tools/bench_encoder_chunk.py) at a tenth of the activation memory; every chunk is normalised straight into its
+        frame range of the output (no torch.cat of the 755 MB feature tensor)."""
         T, _, H, W = frames.shape
         step = max(1, min(int(chunk), int(self.encoder_chunk)))
         out = torch.empty(T, H // self.stride, W // self.stride, self.latent_dim, device=frames.device, dtype=torch.float32)
