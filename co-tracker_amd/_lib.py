@@ -155,6 +155,7 @@ SYMBOLS = {
     "ctk_split_rows": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp]),
     "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
     "ctk_profile_enable": (C.c_int, [C.c_int]),
+    "ctk_gemm_pp_mode": (None, [C.c_int]),
     "ctk_profile_read": (C.c_int, [_P(ProfileRow), C.c_int, _P(C.c_int)]),
     "ctk_probe_mfma": (C.c_int, [C.c_int, C.c_int, _fp, _P(C.c_double), _fp]),
 }

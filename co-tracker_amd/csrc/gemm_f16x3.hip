@@ -529,6 +529,10 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
     return pname;
   };
 
+  if (g.a_split) {  // round 3: persistent ping-pong kernels for the big N % 256 == 0 / N % 192 == 0 Linears
+    const int rc = ctk_launch_gemm_pp(g, flops, bytes, s);
+    if (rc >= 0) return rc;
+  }
   const long blocks128 = (long)((g.M + 127) / 128) * (g.N / 128) * g.batch;
   // 128 x 128 tiles once they fill most of the 512 resident slots, 64 x 64 below (CTK_GEMM_BIG_MIN overrides the threshold)
   static const long big_min = [] { const char* e = getenv("CTK_GEMM_BIG_MIN"); return e ? atol(e) : 384L; }();

@@ -61,3 +61,5 @@ struct CtkGemmP {
 
 // gemm_f16x3.hip
 int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s);
+// gemm_pp.hip: persistent ping-pong kernels; returns -1 when the shape is not theirs (caller falls back)
+int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s);

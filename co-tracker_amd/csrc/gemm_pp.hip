@@ -1,0 +1,653 @@
+// Split-half GEMM, round-3 kernel: ONE persistent 8-wave workgroup per CU, the two waves of every SIMD in
+// anti-phase ("ping-pong").
+//
+// Why (profiles/r02_sq_counters.txt read with MI355X_MICROARCH.md's definitions): in gemm_f16x3.hip's kernels a wave
+// is issue-stalled 61 % of its life while the matrix pipe is idle 55 % of the time -- the co-resident waves of a
+// SIMD run IN PHASE (both in their MFMA burst, then both issuing 8 LDS-DMA pieces at 100-185 cycles each, both
+// reading fragments, both parked at the vmcnt(0) barrier), and a 128x128 tile needs 26 TB/s of L2->LDS traffic at
+// the MFMA ceiling.  This kernel changes the structure, not the arithmetic:
+//   * 256-row tiles, 8 waves = 2 per SIMD in one workgroup; waves 0-3 (group 0) and 4-7 (group 1) run the same
+//     phase sequence one s_barrier apart: while one group issues its 12 MFMAs of a phase (384 matrix-pipe cycles)
+//     the other reads the next fragments from LDS and issues its 2-3 LDS-DMA pieces (cdna_hip_programming.md,
+//     "The 256^2 8-phase template");
+//   * the K-tile (32 f32 columns = one 128-byte SH line per row) is cut into blocks that are each read in exactly
+//     one phase, so the LDS ring (2 K-tiles) is recycled block by block: a block is requested 4-6 phases before it
+//     is read, waited for with a COUNTED s_waitcnt vmcnt (never 0) one phase before, behind raw s_barriers;
+//   * persistent: a workgroup walks over its tiles and the DMA stream simply continues into the next tile, so
+//     only the first tile of a workgroup pays a cold prologue; the two groups run their epilogues one MFMA phase
+//     apart without dropping the stagger;
+//   * two tile shapes with the same per-wave structure: 256 x 256 (waves 2 x 4, wave tile 128 x 64) for
+//     N % 256 == 0 and 256 x 192 (waves 4 x 2, wave tile 64 x 96) for N % 192 == 0 (N = 384: A is fetched
+//     twice instead of three times).
+// Same numerics as gemm_f16x3.hip (3 x v_mfma_f32_32x32x16_f16 per product, small terms first within a k-step).
+#include "ctk_common.h"
+#include "ctk_profile.h"
+#include "gemm_params.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+constexpr int PP_HDR_BYTES = 64;
+constexpr int PP_BIAS_BYTES = 8192;  // the whole bias vector (N <= 2048) staged in LDS once per workgroup
+
+#define PP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PP_WAIT_VM(N)                                              \
+  do {                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");       \
+    PP_SCHED_FENCE();                                              \
+  } while (0)
+#define PP_WAIT_LGKM0()                                            \
+  do {                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+    PP_SCHED_FENCE();                                              \
+  } while (0)
+#define PP_BARRIER()                                               \
+  do {                                                             \
+    PP_SCHED_FENCE();                                              \
+    __builtin_amdgcn_s_barrier();                                  \
+    PP_SCHED_FENCE();                                              \
+  } while (0)
+
+typedef const __attribute__((address_space(1))) void* pp_gptr;
+typedef __attribute__((address_space(3))) void* pp_lptr;
+
+// one LDS-DMA piece: 64 lanes x 16 bytes -> 1 KiB at lds_dst (wave-uniform) + lane * 16
+__device__ __forceinline__ void pp_dma16(const unsigned char* base /*uniform*/, unsigned voff, unsigned char* lds_dst /*uniform*/) {
+  __builtin_amdgcn_global_load_lds((pp_gptr)(base + voff), (pp_lptr)lds_dst, 16, 0, 0);
+}
+
+// ---- epilogue ----------------------------------------------------------------------------------
+// EPI bit layout as gemm_f16x3.hip: act (bits 0-1), residual (2), SH output (3), per-row bias table (4), bias (5).
+constexpr int pp_epi(int act, bool res, bool split, bool brows, bool bias) {
+  return act | (res ? 4 : 0) | (split ? 8 : 0) | (brows ? 16 : 0) | (bias ? 32 : 0);
+}
+
+// acc[mi][ni] is the swapped-operand 32x32 accumulator D'[n][m]: lane = output row r32 (+ row_of(mi)), register quad q =
+// output columns col_of(ni) + 8q + 4*half + 0..3.
+// Stores: written straight from that layout a store instruction touches 32 rows x 32 bytes, and a CU retires such an
+// instruction only every ~100 cycles -- measured in tools/gemm_lab.cpp (profiles/r03_gemm_lab_store_experiments.txt): the
+// SAME bytes as one contiguous KiB per instruction cost a third.  So every 32x32 sub-tile (f32: 32 rows x 128 B; SH: the
+// row's 128-byte line = 32 hi | 32 lo halves) goes through a wave-private 4 KiB LDS image (16-byte chunk c of row r at
+// position c ^ (r & 7): conflict-free writes) and leaves as 4 dwordx4 stores of 8 full 128-byte lines each.
+// The bias vector lives in LDS too (bias_lds, staged once per workgroup): an ordinary global load in the epilogue would
+// make hipcc drain the whole LDS-DMA queue (vmcnt(0)) at its first use AND at the top of the next tile.  The residual
+// (EPI bit 2) is not added here: pp_init_acc preloads it, scaled, into the accumulators at the start of the tile.
+template <int EPI, int MI, int NI, class RowOf, class ColOf>
+__device__ __forceinline__ void pp_epilogue(const CtkGemmP& g, f32x16 (&acc)[MI][NI], const int lane, const int bz, const float unscale,
+                                            const float* bias_lds, unsigned char* scratch /* 4 KiB, this wave's */, RowOf row_of,
+                                            ColOf col_of, const bool no_store = false) {
+  constexpr int ACT = EPI & 3;
+  constexpr bool SPLIT = (EPI & 8) != 0, BROWS = (EPI & 16) != 0, BIAS = (EPI & 32) != 0;
+  const int r32 = lane & 31, half = lane >> 5;
+  f32x4 bv[NI][4];
+  if (BIAS) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[ni][q] = *reinterpret_cast<const f32x4*>(bias_lds + col_of(ni) + q * 8 + half * 4);
+  }
+  unsigned char* wr = scratch + r32 * 128;  // my row of the image
+  const int wsw = r32 & 7;
+  const int rrow = lane >> 3, rchunk = lane & 7;  // read-back: 8 lanes per row, 8 rows per instruction
+  const unsigned char* rd = scratch + rrow * 128 + ((rchunk ^ rrow) << 4);
+  const bool full = row_of(MI - 1) + 32 <= g.M;   // wave-uniform: no row of this wave's tile is beyond M
+  const long row_step = (long)8 * g.ldc * (SPLIT ? 2 : 4);
+  // software pipeline over the MI x NI sub-tiles: the 4 read-backs of sub-tile k are issued right behind its writes (the LDS
+  // serves a wave's accesses in order) and stored one sub-tile later, behind the next sub-tile's arithmetic
+  f32x4 pend[4];
+  unsigned char* pend_dst = nullptr;
+  int pend_row0 = 0;
+  auto flush = [&]() {
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(pend_dst + i * row_step) = pend[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (pend_row0 + 8 * i < g.M) *reinterpret_cast<f32x4*>(pend_dst + i * row_step) = pend[i];
+    }
+  };
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int rowc = min(row_of(mi) + r32, g.M - 1);
+    const float* bp = BROWS ? g.bias_rows + (long)(rowc % g.bias_period) * g.N + half * 4 : nullptr;
+    unsigned char* crow = static_cast<unsigned char*>(g.C) + ((long)bz * g.c_bs + (long)(row_of(mi) + rrow) * g.ldc) * (SPLIT ? 2 : 4) + rchunk * 16;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][q * 4 + e] * unscale;
+        if (BIAS) v += bv[ni][q];
+        if (BROWS) v += *reinterpret_cast<const f32x4*>(bp + col_of(ni) + q * 8);
+        if (ACT == CTK_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_erf(v[e]);
+        } else if (ACT == CTK_ACT_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ctk_gelu_tanh(v[e]);
+        }
+        if (SPLIT) {  // line = 8 chunks: hi halves of columns 8c..8c+7 in chunk c, lo halves in chunk 4 + c
+          f16x4 hi, lo;
+          ctk_split4(v, hi, lo);
+          *reinterpret_cast<f16x4*>(wr + ((q ^ wsw) << 4) + half * 8) = hi;
+          *reinterpret_cast<f16x4*>(wr + (((4 + q) ^ wsw) << 4) + half * 8) = lo;
+        } else {      // line = 32 floats: columns 4c..4c+3 in chunk c = 2q + half
+          *reinterpret_cast<f32x4*>(wr + (((2 * q + half) ^ wsw) << 4)) = v;
+        }
+      }
+      if (mi + ni > 0 && !no_store) flush();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pend[i] = *reinterpret_cast<const f32x4*>(rd + i * 1024);
+      // column offset of this sub-tile inside the output row: SH = (col/32) lines of 128 B, f32 = col * 4 B -- the same number
+      pend_dst = crow + (long)col_of(ni) * 4;
+      pend_row0 = row_of(mi) + rrow;
+    }
+  }
+  if (!no_store) flush();
+}
+
+template <int EPI>
+__device__ __forceinline__ void pp_stage_bias(const CtkGemmP& g, unsigned char* dst, const int tid) {
+  if ((EPI & 32) != 0) {
+    for (int i = tid; i < g.N / 4; i += 512) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(g.bias)[i];
+    __syncthreads();  // before any LDS-DMA is in flight: a plain barrier with full waits
+  }
+}
+
+// Accumulator start values of a tile: 0, or (EPI bit 2) the residual tile times the weight scale s -- the epilogue's
+// "* 1/s" then returns it exactly (s is a power of two) and the loads have the whole main loop to land.
+template <int EPI, int MI, int NI, class RowOf, class ColOf>
+__device__ __forceinline__ void pp_init_acc(const CtkGemmP& g, f32x16 (&acc)[MI][NI], const int r32, const int half, const int bz,
+                                            const float scale, RowOf row_of, ColOf col_of) {
+  constexpr bool RES = (EPI & 4) != 0;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int rowc = min(row_of(mi) + r32, g.M - 1);
+    const float* rp = RES ? g.resid + (long)bz * g.c_bs + (long)rowc * g.ldr + half * 4 : nullptr;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (RES) v = *reinterpret_cast<const f32x4*>(rp + col_of(ni) + q * 8) * scale;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mi][ni][q * 4 + e] = v[e];
+      }
+  }
+}
+
+// ---- tile walk -----------------------------------------------------------------------------------
+// Persistent workgroup b of G walks over rounds r = 0, 1, ...: in round r the G (or fewer) tiles [r*G, r*G + n_r) are dealt
+// so that XCD x (workgroup b sits on XCD b % 8) gets a contiguous run of logical tiles (neighbours share A rows / W in its L2).
+struct PPTile {
+  const unsigned char* a;  // A rows of the tile, K-tile 0 (bytes)
+  const unsigned char* w;  // W rows of the tile, K-tile 0
+  int m0, n0, bz;
+  unsigned lim;            // last valid row inside the tile (rows beyond M are clamped, never stored)
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ bool pp_tile(const CtkGemmP& g, int tiles_total, int q, PPTile& t) {
+  const int G = gridDim.x, b = blockIdx.x;
+  const int first = q * G;
+  if (first >= tiles_total) return false;
+  const int n_r = min(G, tiles_total - first);
+  if (b >= n_r) return false;
+  unsigned tile = first + ctk_xcd_remap(b, n_r);
+  const int nb = tile % g.nblocks;
+  tile /= g.nblocks;
+  const int mb = tile % g.mblocks;
+  t.bz = tile / g.mblocks;
+  t.m0 = mb * BM;
+  t.n0 = nb * BN;
+  const int KT = g.K / 32;
+  t.a = reinterpret_cast<const unsigned char*>(g.A) + ((long)t.bz * g.a_bs + (long)t.m0 * g.lda) * 2;
+  t.w = reinterpret_cast<const unsigned char*>(g.Wp) + PP_HDR_BYTES + (long)t.n0 * KT * 128;
+  t.lim = (unsigned)min(BM - 1, g.M - 1 - t.m0);
+  return true;
+}
+
+// DMA cursor: one K-tile of the workgroup's stream (tile q, K-tile kt); saturates at the end of the stream (the ring
+// then receives harmless duplicate blocks, which keeps every vmcnt count of the steady state valid in the tail).
+struct PPCursor {
+  const unsigned char* a;
+  const unsigned char* w;
+  unsigned lim;
+  int q, kt;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void pp_cursor_next(const CtkGemmP& g, int tiles_total, int KT, PPCursor& c) {
+  if (c.kt + 1 < KT) {
+    c.kt += 1;
+    c.a += 128;
+    c.w += 128;
+  } else {
+    PPTile t;
+    if (pp_tile<BM, BN>(g, tiles_total, c.q + 1, t)) {
+      c.q += 1;
+      c.kt = 0;
+      c.a = t.a;
+      c.w = t.w;
+      c.lim = t.lim;
+    }
+  }
+}
+
+// ================================================================================================
+// 256 x 256 tile.  waves 2 (M) x 4 (N); wave (wm, wn) owns rows {a*128 + wm*64 + mi*32 + [0,32)} and columns
+// {b*128 + wn*32 + [0,32)} for a, mi, b in {0,1}: each 128-row half of the A tile and each 128-row half of the W tile is
+// one BLOCK (16 KiB, 16 LDS-DMA pieces, 2 per wave), and phase (a, b) of a K-tile -- 2 x 1 accumulators x 2 k-steps x 3
+// terms = 12 MFMAs -- reads block A_a and block B_b only.  Phase order (0,0) (0,1) (1,1) (1,0): the A fragments are read
+// in phases 0 and 2, B_0 in phase 0 (kept for phase 3), B_1 in phase 1.
+// Stream of blocks: i = 4 J + {0: A_0, 1: B_0, 2: B_1, 3: A_1} (J = K-tile of the workgroup's stream); block i is read in
+// phase <= i, issued in the load segment of phase i - 6 (slot = that of block i - 8, last read >= 2 phases earlier) and
+// every wave has waited for its pieces of blocks <= g + 2 at the end of the load segment of phase g (vmcnt(8): the 4
+// younger blocks stay in flight), one s_barrier before any wave reads them.
+// LDS: A blocks at (J&1)*32K + a*16K, B blocks at 64K + (J&1)*32K + b*16K.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_total, int dbg) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int RING = 131072;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + PP_BIAS_BYTES];  // ONE LDS object (a second one makes hipcc drain vmcnt before ds_reads)
+
+  const int KT = g.K / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;  // ping-pong group (waves w and w + 4 share a SIMD)
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  PPTile tile;
+  if (!pp_tile<BM, BN>(g, tiles_total, 0, tile)) return;
+  const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
+  const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
+  pp_stage_bias<EPI>(g, lds + RING, tid);
+  if (dbg >> 8) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
+    const int n = ((blockIdx.x >> 3) & 3) * (dbg >> 8);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
+  // ---- DMA addressing.  Piece p = 2*wave + e of a block covers block rows 8p + (lane >> 3); lane position (lane & 7) of a row
+  // receives source chunk (lane & 7) ^ f(row), f(r) = (r >> 1) & 7 (undone by the fragment reads).
+  const unsigned prow = 16 * wave + (lane >> 3);                       // e = 0 row inside the block
+  const unsigned cb0 = (((lane & 7) ^ ((lane >> 4) & 7)) << 4);       // f(row) for e = 0: ((16w + (lane>>3)) >> 1) & 7 = lane >> 4
+  const unsigned cb1 = cb0 ^ 64;                                       // e = 1: rows + 8 -> f ^ 4
+  const unsigned lda_b = (unsigned)g.lda * 2;                          // bytes per A row
+  const unsigned ldw_b = (unsigned)KT * 128;                           // bytes per packed W row
+  const unsigned wv0 = prow * ldw_b + cb0, wv1 = (prow + 8) * ldw_b + cb1;
+
+  auto dma_a = [&](const PPCursor& c, const int a, const int par) {
+    unsigned char* dst = lds + par * 32768 + a * 16384 + wave * 2048;
+    const unsigned r0 = min(prow + a * 128, c.lim), r1 = min(prow + a * 128 + 8, c.lim);
+    pp_dma16(c.a, r0 * lda_b + cb0, dst);
+    pp_dma16(c.a, r1 * lda_b + cb1, dst + 1024);
+  };
+  auto dma_b = [&](const PPCursor& c, const int b, const int par) {
+    unsigned char* dst = lds + 65536 + par * 32768 + b * 16384 + wave * 2048;
+    const unsigned char* src = c.w + (long)b * 128 * ldw_b;
+    pp_dma16(src, wv0, dst);
+    pp_dma16(src, wv1, dst + 1024);
+  };
+
+  // ---- fragment addressing: row r of a block, data chunk c = plane*4 + j*2 + half at r*128 + ((c ^ f(r)) << 4)
+  const int fsw = (r32 >> 1) & 7;
+  unsigned a_rd[2][2], b_rd[2][2];  // [j][plane], including the K-tile parity bit (32 KiB)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const unsigned co = (unsigned)(((p * 4 + j * 2 + half) ^ fsw) << 4);
+      a_rd[j][p] = (wm * 64 + r32) * 128 + co;
+      b_rd[j][p] = 65536 + (wn * 32 + r32) * 128 + co;
+    }
+
+  f16x8 fa[2][2][2];   // [mi][j][plane]
+  f16x8 fb[2][2][2];   // [b][j][plane]
+  auto read_a = [&](const int a) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) fa[mi][j][p] = *reinterpret_cast<const f16x8*>(lds + a_rd[j][p] + a * 16384 + mi * 4096);
+  };
+  auto read_b = [&](const int b) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) fb[b][j][p] = *reinterpret_cast<const f16x8*>(lds + b_rd[j][p] + b * 16384);
+  };
+
+  f32x16 acc[4][2];  // [a*2 + mi][b]
+  auto row_of = [&](int i) { return tile.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; };
+  auto col_of = [&](int b) { return tile.n0 + wn * 32 + b * 128; };
+  auto init_acc = [&]() { pp_init_acc<EPI, 4, 2>(g, acc, r32, half, tile.bz, w_scale, row_of, col_of); };
+  // operands swapped on purpose (D'[n][m]: lane = output row, register quad = 4 consecutive columns); small terms first
+  auto mma = [&](const int a, const int b) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[a * 2 + mi][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[b][j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0],
+                                                                      acc[a * 2 + mi][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- stream set-up: blocks 0..5 = K-tile 0 (all four) + K-tile 1 (A_0, B_0)
+  PPCursor c1, c2;  // K-tiles J+1 and J+2 of the stream
+  {
+    PPCursor c0{tile.a, tile.w, tile.lim, 0, 0};
+    dma_a(c0, 0, 0);
+    dma_b(c0, 0, 0);
+    dma_b(c0, 1, 0);
+    dma_a(c0, 1, 0);
+    c1 = c0;
+    pp_cursor_next<BM, BN>(g, tiles_total, KT, c1);
+    dma_a(c1, 0, 1);
+    dma_b(c1, 0, 1);
+    c2 = c1;
+    pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+  }
+  init_acc();
+  PP_WAIT_VM(8);   // blocks 0, 1 (K-tile 0: A_0, B_0) have landed
+  PP_BARRIER();
+  if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one barrier behind group 0
+
+  int par = 0;
+  for (int q = 0;; ++q) {  // my tiles
+    for (int kt = 0; kt < KT; ++kt) {
+      // ---- phase 0 (a=0, b=0): read A_0, B_0; issue B_1 of K-tile J+1
+      read_a(0);
+      read_b(0);
+      dma_b(c1, 1, par ^ 1);
+      PP_WAIT_VM(8);
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      mma(0, 0);
+      PP_BARRIER();
+      // ---- phase 1 (a=0, b=1): read B_1; issue A_1 of K-tile J+1
+      read_b(1);
+      dma_a(c1, 1, par ^ 1);
+      PP_WAIT_VM(8);
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      mma(0, 1);
+      PP_BARRIER();
+      // ---- phase 2 (a=1, b=1): read A_1; issue A_0 of K-tile J+2 (into the slot A_0 of this K-tile left in phase 0)
+      read_a(1);
+      dma_a(c2, 0, par);
+      PP_WAIT_VM(8);
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      mma(1, 1);
+      PP_BARRIER();
+      // ---- phase 3 (a=1, b=0): nothing to read (B_0 is still in registers); issue B_0 of K-tile J+2
+      dma_b(c2, 0, par);
+      PP_WAIT_VM(8);
+      const bool last = kt + 1 == KT;
+      PP_BARRIER();
+      mma(1, 0);
+      if (!last) PP_BARRIER();
+      // advance the stream
+      c1 = c2;
+      pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+      par ^= 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          a_rd[j][p] ^= 32768;
+          b_rd[j][p] ^= 32768;
+        }
+    }
+    // ---- epilogue: group 0 after the phase's closing barrier, group 1 before it -- both write their tile at the same
+    // time (one MFMA phase apart) and the stagger survives into the next tile
+    if (grp == 0) PP_BARRIER();
+    // wave-private 4 KiB for the store transposes: two ring slots are idle here -- B_1 and A_1 of the K-tile just finished
+    // (the next blocks that land there, B_1 / A_1 of K-tile J+2, are issued in phases 0 / 1 of the next K-tile, which each
+    // group enters only after its own epilogue, and the other group only after a barrier behind this epilogue)
+    pp_epilogue<EPI, 4, 2>(g, acc, lane, tile.bz, w_unscale, bias_lds,
+                           lds + (grp == 0 ? 65536 : 0) + (par ^ 1) * 32768 + 16384 + (wave & 3) * 4096, row_of, col_of, (dbg & 2) != 0);
+    const bool more = pp_tile<BM, BN>(g, tiles_total, q + 1, tile);
+    init_acc();  // unconditional (a conditional re-init doubles the live accumulators at the merge); on the last tile it re-reads valid addresses
+    if (grp == 1) PP_BARRIER();
+    if (!more) break;
+  }
+  if (grp == 0) PP_BARRIER();  // balance group 1's extra barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // duplicate tail blocks may still be landing
+}
+
+// ================================================================================================
+// 256 x 192 tile (N = 384 as two column halves).  waves 4 (M) x 2 (N); wave (wm, wn) owns rows wm*64 + mi*32 + [0,32)
+// (mi < 2) and columns ni*64 + wn*32 + [0,32) (ni < 3).  Phase n of a K-tile = accumulators (mi, ni = n), 12 MFMAs:
+// phase 0 reads the wave's A fragments (kept for the K-tile) and B_0, phase 1 B_1, phase 2 B_2 (B_n = the 64 W rows of
+// column block n, 8 KiB).  Per K-tile 56 pieces in order of need -- A (32), B_0 (8), B_1 (8), B_2 (8) -- issued as
+// three blocks I0 = A pieces 0..23 (3 per wave), I1 = A pieces 24..31 + B_0 (2 per wave), I2 = B_1 + B_2 (2 per wave);
+// block i = 3 J + k is issued in phase i - 4 into the K-tile slot (J & 1) (56 KiB each), where block i - 6 was last read
+// >= 2 phases earlier; waits: end of phase 3J+2 -> I0, I1 of K-tile J+1 (vmcnt(5): I2(J+1) and I0(J+2) stay in flight),
+// end of phase 3J -> I2 of K-tile J (vmcnt(5)), end of phase 3J+1 -> nothing new.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_total, int dbg) {
+  constexpr int BM = 256, BN = 192;
+  constexpr int SLOT = 57344;  // 32 KiB A + 3 x 8 KiB B
+  constexpr int RING = 2 * SLOT;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + PP_BIAS_BYTES + 8 * 4096];  // ring | bias | store-transpose scratch
+
+  const int KT = g.K / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  PPTile tile;
+  if (!pp_tile<BM, BN>(g, tiles_total, 0, tile)) return;
+  const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
+  const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
+  pp_stage_bias<EPI>(g, lds + RING, tid);
+  if (dbg >> 8) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
+    const int n = ((blockIdx.x >> 3) & 3) * (dbg >> 8);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
+  // ---- DMA addressing.  A piece p covers tile rows 8p + (lane>>3) -> LDS p*1024; f(row) = (row >> 1) & 7 = (4p + (lane >> 4)) & 7.
+  const unsigned l3 = lane >> 3, l4 = lane >> 4, l7 = lane & 7;
+  const unsigned lda_b = (unsigned)g.lda * 2;
+  const unsigned ldw_b = (unsigned)KT * 128;
+  auto cbyte = [&](const int piece) { return ((l7 ^ ((4 * piece + l4) & 7)) << 4); };
+  auto dma_a_piece = [&](const PPCursor& c, const int piece, const int par) {  // piece: uniform
+    const unsigned r = min((unsigned)(8 * piece) + l3, c.lim);
+    pp_dma16(c.a, r * lda_b + cbyte(piece), lds + par * SLOT + piece * 1024);
+  };
+  // B_n piece p (0..7) covers W rows n*64 + 8p + (lane>>3) -> LDS 32768 + n*8192 + p*1024; swizzle by the row inside B_n
+  auto dma_b_piece = [&](const PPCursor& c, const int n, const int piece, const int par) {
+    const unsigned r = (unsigned)(n * 64 + 8 * piece) + l3;
+    pp_dma16(c.w, r * ldw_b + cbyte(piece), lds + par * SLOT + 32768 + n * 8192 + piece * 1024);
+  };
+  auto issue_i0 = [&](const PPCursor& c, const int par) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) dma_a_piece(c, 3 * wave + e, par);
+  };
+  auto issue_i1 = [&](const PPCursor& c, const int par) {
+    if (wave < 4) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) dma_a_piece(c, 24 + 2 * wave + e, par);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) dma_b_piece(c, 0, 2 * (wave - 4) + e, par);
+    }
+  };
+  auto issue_i2 = [&](const PPCursor& c, const int par) {
+    const int n = wave < 4 ? 1 : 2, w4 = wave & 3;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) dma_b_piece(c, n, 2 * w4 + e, par);
+  };
+
+  // ---- fragment addressing
+  const int fsw = (r32 >> 1) & 7;
+  unsigned a_rd[2][2], b_rd[2][2];
+  auto set_rd = [&](const int par) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const unsigned co = (unsigned)(((p * 4 + j * 2 + half) ^ fsw) << 4);
+        a_rd[j][p] = par * SLOT + (wm * 64 + r32) * 128 + co;
+        b_rd[j][p] = par * SLOT + 32768 + (wn * 32 + r32) * 128 + co;
+      }
+  };
+  f16x8 fa[2][2][2];  // [mi][j][plane]
+  f16x8 fb[2][2];     // [j][plane] of the current column block
+  auto read_a = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) fa[mi][j][p] = *reinterpret_cast<const f16x8*>(lds + a_rd[j][p] + mi * 4096);
+  };
+  auto read_b = [&](const int n) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) fb[j][p] = *reinterpret_cast<const f16x8*>(lds + b_rd[j][p] + n * 8192);
+  };
+
+  f32x16 acc[2][3];
+  auto row_of = [&](int mi) { return tile.m0 + wm * 64 + mi * 32; };
+  auto col_of = [&](int ni) { return tile.n0 + wn * 32 + ni * 64; };
+  auto init_acc = [&]() { pp_init_acc<EPI, 2, 3>(g, acc, r32, half, tile.bz, w_scale, row_of, col_of); };
+  auto mma = [&](const int n) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][n], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- stream set-up: blocks 0..3 = K-tile 0 (I0, I1, I2) + I0 of K-tile 1
+  PPCursor c1, c2;
+  {
+    PPCursor c0{tile.a, tile.w, tile.lim, 0, 0};
+    issue_i0(c0, 0);
+    issue_i1(c0, 0);
+    issue_i2(c0, 0);
+    c1 = c0;
+    pp_cursor_next<BM, BN>(g, tiles_total, KT, c1);
+    issue_i0(c1, 1);
+    c2 = c1;
+    pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+  }
+  init_acc();
+  set_rd(0);
+  PP_WAIT_VM(5);  // I0, I1 of K-tile 0 landed (I2: 2 pieces and I0 of K-tile 1: 3 pieces may be in flight)
+  PP_BARRIER();
+  if (grp == 1) PP_BARRIER();
+
+  int par = 0;
+  for (int q = 0;; ++q) {
+    for (int kt = 0; kt < KT; ++kt) {
+      // ---- phase 0: read A, B_0; issue I1 of K-tile J+1; wait for I2 of this K-tile
+      read_a();
+      read_b(0);
+      issue_i1(c1, par ^ 1);
+      PP_WAIT_VM(5);
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      mma(0);
+      PP_BARRIER();
+      // ---- phase 1: read B_1; issue I2 of K-tile J+1
+      read_b(1);
+      issue_i2(c1, par ^ 1);
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      mma(1);
+      PP_BARRIER();
+      // ---- phase 2: read B_2; issue I0 of K-tile J+2 (the A rows of this K-tile were read in phase 0); wait for I0, I1 of J+1
+      read_b(2);
+      issue_i0(c2, par);
+      PP_WAIT_VM(5);
+      const bool last = kt + 1 == KT;
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      mma(2);
+      if (!last) PP_BARRIER();
+      c1 = c2;
+      pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+      par ^= 1;
+      set_rd(par);
+    }
+    if (grp == 0) PP_BARRIER();
+    pp_epilogue<EPI, 2, 3>(g, acc, lane, tile.bz, w_unscale, bias_lds, lds + RING + PP_BIAS_BYTES + wave * 4096, row_of, col_of, (dbg & 2) != 0);
+    const bool more = pp_tile<BM, BN>(g, tiles_total, q + 1, tile);
+    init_acc();  // unconditional (a conditional re-init doubles the live accumulators at the merge); on the last tile it re-reads valid addresses
+    if (grp == 1) PP_BARRIER();
+    if (!more) break;
+  }
+  if (grp == 0) PP_BARRIER();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int pp_num_cus() {
+  static const int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    return cu;
+  }();
+  return n;
+}
+
+int g_pp_mode = 1;  // bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; experiments: bit 1 = no stores, bits 8.. = start stagger
+
+}  // namespace
+
+extern "C" void ctk_gemm_pp_mode(int mode) { g_pp_mode = mode; }
+
+// Returns CTK_OK after launching, or -1 when the shape is not one of the persistent kernels' (caller falls back).
+int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
+  if ((g_pp_mode & 1) == 0 || !g.a_split || !g.Wp) return -1;
+  const bool t256 = (g.N % 256) == 0, t192 = !t256 && (g.N % 192) == 0;
+  if ((!t256 && !t192) || g.N * 4 > PP_BIAS_BYTES) return -1;
+  if (g.lda * 2 > 0xffffff) return -1;  // row offsets are formed with 32-bit arithmetic inside a tile
+  const int BN = t256 ? 256 : 192;
+  g.mblocks = (g.M + 255) / 256;
+  g.nblocks = g.N / BN;
+  const long tiles = (long)g.mblocks * g.nblocks * g.batch;
+  const int cus = pp_num_cus();
+  if (tiles < cus) return -1;  // less than one tile per CU (virtual-track GEMMs, short streaming windows): the 64x64 / 128x128 kernels fill the chip better (tools/gemm_lab.cpp)
+  char pname[40];
+  snprintf(pname, sizeof(pname), "gemm_sh_pp%d_k%d_n%d", BN, g.K, g.N);
+  CtkProfScope ps(pname, flops, bytes, s);
+  const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), blk(512);
+  const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
+  if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
+#define PP_CASE(E)                                                                                   \
+  case E:                                                                                            \
+    if (t256) hipLaunchKernelGGL((gemm_pp256_kernel<E>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);            \
+    else hipLaunchKernelGGL((gemm_pp192_kernel<E>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);                 \
+    break
+  switch (code) {
+    PP_CASE(pp_epi(CTK_ACT_GELU_ERF, false, true, false, true));    // corr_mlp.fc1
+    PP_CASE(pp_epi(CTK_ACT_NONE, false, true, false, true));        // corr_mlp.fc2 -> x (SH)
+    PP_CASE(pp_epi(CTK_ACT_NONE, false, false, true, false));       // input_transform (+ per-frame bias rows)
+    PP_CASE(pp_epi(CTK_ACT_NONE, false, false, false, true));       // to_q / to_kv
+    PP_CASE(pp_epi(CTK_ACT_NONE, true, false, false, true));        // to_out / mlp.fc2 (+ residual)
+    PP_CASE(pp_epi(CTK_ACT_GELU_TANH, false, true, false, true));   // mlp.fc1
+    default:
+      return -1;
+  }
+#undef PP_CASE
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}

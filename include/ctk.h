@@ -362,6 +362,9 @@ typedef struct ctk_profile_row {
   double bytes;
 } ctk_profile_row;
 int ctk_profile_enable(int on);
+/* Dev / A-B knob (process-global, not thread-safe): 1 (default) = the big split-half Linears (N % 256 == 0 or N % 192 == 0,
+ * >= 128 tiles of 256 rows) run on the persistent ping-pong kernels of gemm_pp.hip, 0 = always gemm_f16x3.hip's kernels. */
+void ctk_gemm_pp_mode(int mode);
 int ctk_profile_read(ctk_profile_row* rows, int max_rows, int* nrows);
 /* Register-only MFMA loop (2 workgroups x 4 waves per CU) to calibrate the sustained peak of this
  * chip under its power budget: kind 0 = v_mfma_f32_32x32x2_f32, 1 = v_mfma_f32_32x32x16_bf16.     */

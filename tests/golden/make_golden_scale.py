@@ -46,7 +46,29 @@ CONFIGS = {
     # only the already-queried tracks, the 6x6 support grid the predictor appends, backward tracking (a second, time-flipped
     # model pass merged for the frames before each query)
     "c3_q": (512, 512, 64, 32, "queries", 16, 8, 3),
+    # round 3: the BASELINE configs that were benchmarked without a reference golden
+    # configs[0] stand-in: assets/apple.mp4 is 1296x720, 50 frames, but no video decoder exists offline -> a synthetic video of
+    # exactly that size through hubconf's cotracker3_offline recipe (CoTrackerPredictor(offline=True, window_len=60)), grid 10
+    "c1": (720, 1296, 50, 10, "offline", 60, 8, 1),
+    # configs[2] video as ONE offline window of 120 frames (cotracker3_offline.py:139-216), N=1600
+    "c3_off": (512, 512, 120, 40, "offline", 60, 8, 3),
+    # configs[4], the per-GPU unit of work: chunk 0 (8 779 points) of the 265x265 quasi-dense grid, explicit queries at
+    # frame 0, sliding windows (bench.py --workload c5_shard, rank 0); every 4th point is stored
+    "c5_chunk0": (512, 512, 120, 265, "chunk0", 16, 8, 5),
 }
+STORE_EVERY = {"c3_g80": 4, "c5_chunk0": 4}  # jointly tracked, every k-th point stored (fixture size)
+
+
+def c5_chunk0_queries(H, W, G, interp_shape=(384, 512)):
+    """bench.py's c5_shard queries of rank 0, computed on the CPU with the REFERENCE's grid helper."""
+    from cotracker.models.core.model_utils import get_points_on_a_grid
+    from cotracker_amd.sharding import chunk_bounds
+    ih, iw = interp_shape
+    to_raw = torch.tensor([(W - 1) / (iw - 1), (H - 1) / (ih - 1)])
+    pts = get_points_on_a_grid(G, (ih, iw)) * to_raw
+    q_all = torch.cat([torch.zeros_like(pts[:, :, :1]), pts], dim=2)
+    lo, hi = chunk_bounds(G * G, 8, 0)
+    return q_all[:, lo:hi].contiguous()
 
 
 class SigmoidTap:
@@ -98,6 +120,10 @@ def run(name, threads):
             q[0, : n // 4, 0] = 0
             tracks, vis = p(video, queries=q, backward_tracking=True)
             captured["coords"] = tracks  # two model passes are merged: the predictor-level tracks are the comparable output
+        elif kind == "chunk0":
+            q = c5_chunk0_queries(H, W, G)
+            captured["queries"] = q
+            tracks, vis = p(video, queries=q)
         elif kind == "online":
             p(video_chunk=video[:, :2 * p.step], is_first_step=True, grid_size=G)
             for ind in range(0, T - p.step, p.step):
@@ -109,7 +135,10 @@ def run(name, threads):
     out = dict(coords=captured["coords"][0], vis_logit=vis_logit[0].reshape(vis_logit.shape[1], -1),
                conf_logit=conf_logit[0].reshape(conf_logit.shape[1], -1), tracks=tracks[0], vis=vis[0])
     out = {k: v.cpu().numpy() for k, v in out.items()}
-    print(f"{name}: threads={threads} {dt:.1f} s  {T * G * G / dt:.1f} tracked-point-frames/s", flush=True)
+    out["n_points_total"] = np.int64(out["coords"].shape[1])
+    if "queries" in captured:
+        out["queries"] = captured["queries"][0].numpy()
+    print(f"{name}: threads={threads} {dt:.1f} s  {T * out['coords'].shape[1] / dt:.1f} tracked-point-frames/s", flush=True)
     return out, dt
 
 
@@ -126,6 +155,14 @@ def main():
             stats[f"noise_{k}_median"] = np.median(d)
         stats["noise_vis_flips"] = int((a["vis"] != b["vis"]).sum())
         print(name, {k: float(v) for k, v in stats.items()}, flush=True)
+        every = STORE_EVERY.get(name, 1)
+        if every > 1:  # the noise statistics above are over ALL points; the stored outputs are a strided subset
+            idx = np.arange(0, a["coords"].shape[1], every, dtype=np.int32)
+            stats["vis_true_count"] = int(a["vis"].sum())
+            stats["point_index"] = idx
+            for k in ("coords", "vis_logit", "conf_logit"):
+                a[k] = a[k][:, idx]
+            a.pop("tracks"), a.pop("vis")
         path = os.path.join(HERE, f"scale_{name}.npz")
         np.savez_compressed(path, **a, **stats, threads=th, noise_threads=nth, seconds=dt, noise_seconds=dtn,
                             host_cpus=os.cpu_count(),
