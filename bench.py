@@ -43,6 +43,11 @@ WORKLOADS = {
     "c3_sliding": (512, 512, 120, 80, False, 16, "512x512 T=120 N=6400 cotracker3 online-weights sliding window S=16 (BASELINE.json configs[2])"),
     "c3_offline": (512, 512, 120, 80, True, 60, "512x512 T=120 N=6400 cotracker3_offline single window S=120"),
     "c2_offline": (256, 256, 48, 20, True, 60, "256x256 T=48 N=400 cotracker3_offline (BASELINE.json configs[1])"),
+    # BASELINE.json configs[0] stand-in: assets/apple.mp4 is 1296x720, 50 frames, but there is no video decoder offline ->
+    # a synthetic video of exactly that geometry through the hub recipe (cotracker3_offline, grid_size=10)
+    "c1_standin": (720, 1296, 50, 10, True, 60, "720x1296 T=50 N=100 cotracker3_offline, grid_size=10 (BASELINE.json configs[0] stand-in: apple.mp4's geometry, synthetic pixels)"),
+    # the offline single-window mode at the size the reference itself was run at (62 GB host): parity of the timed step
+    "c3_offline_g40": (512, 512, 120, 40, True, 60, "512x512 T=120 N=1600 cotracker3_offline single window S=120"),
     "c4_online": (512, 512, 0, 32, False, 16, "512x512 cotracker3_online streaming, 16-frame chunks advancing 8, N=1024, "
                   "window replayed as ONE hipGraph per chunk (BASELINE.json configs[3])"),
     # BASELINE.json configs[4]: the 265x265 quasi-dense grid (N=70 225) in 8 contiguous chunks (sharding.chunk_bounds),
@@ -105,6 +110,9 @@ def cpu_baseline(workload):
                 "sample": f"failed: {type(e).__name__}: {e}"}
     res = {"value": r["tracked_point_frames_per_s"], "unit": "tracked-point-frames/s", "cores": r["threads"],
            "kind": "port-torch", "host_logical_cpus": os.cpu_count(), "seconds": r["seconds"],
+           # the sample is the bench workload's video size / window length / weights at FEWER frames and points (a ~10-30 s CPU
+           # budget); it is NOT the headline configuration and the value is not rescaled to it
+           "sample_is_config": False, "sample_frames": r["frames"], "sample_points": r["points"],
            "sample": f"oracle/torch_port.py predictor path incl. encoder, {kind}, {r['video'][0]}x{r['video'][1]} video, "
                      f"T={r['frames']}, N={r['points']} (grid {grid}), 6 iterations, {r['threads']} threads, glibc malloc "
                      f"tuned ({r['malloc_tuned']}): {r['seconds']} s; value = N*T/s of that sample (not rescaled)"}
@@ -113,7 +121,7 @@ def cpu_baseline(workload):
     try:
         import numpy as np
         ref = {}
-        for name in ("c2", "c4", "c3_g40", "c3_g80"):
+        for name in ("c1", "c2", "c4", "c3_g40", "c3_g80", "c3_off", "c5_chunk0"):
             f = os.path.join(ROOT, "tests", "golden", f"scale_{name}.npz")
             if os.path.exists(f):
                 g = np.load(f)
@@ -254,7 +262,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        if "WORLD_SIZE" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU over RCCL, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -312,13 +329,26 @@ def main():
         # chunk r as ONE model call (the virtual tracks couple the points of a call: a chunk is a call, predictor.py:80-96)
         if world > 8:
             raise SystemExit("c5_shard defines 8 chunks")
-        pts = get_points_on_a_grid(G, (ih, iw), device=dev) * to_raw
+        # built on the CPU with the arithmetic of tests/golden/make_golden_scale.py (c5_chunk0), then uploaded: the parity of
+        # the timed step needs bit-identical queries
+        pts = get_points_on_a_grid(G, (ih, iw), device=torch.device("cpu")) * to_raw.cpu()
         q_all = torch.cat([torch.zeros_like(pts[:, :, :1]), pts], dim=2)
         lo, hi = chunk_bounds(N, 8, rank)
-        q = q_all[:, lo:hi].contiguous()
+        q = q_all[:, lo:hi].contiguous().to(dev)
         n_per_rank = hi - lo
         sharding = f"chunk {rank} of 8 per rank ({world} of 8 chunks tracked: {'the whole job' if world == 8 else 'per-GPU rate of the 8-GPU job'})"
         n_gather = sum(chunk_bounds(N, 8, r)[1] - chunk_bounds(N, 8, r)[0] for r in range(world))
+
+        model_fwd = pred.model.forward
+        tap = {}
+
+        def tapped(*a, **k):
+            o = model_fwd(*a, **k)
+            tap["coords"] = o[0].clone()
+            return o
+
+        if world == 1:
+            pred.model.forward = tapped
 
         def local_step():
             return pred(video, queries=q)
@@ -376,6 +406,17 @@ def main():
     sec_per_step = float(tmax.item()) / args.steps
     assert torch.isfinite(out[0]).all()
     assert pred.model.range_fallbacks == 0 if hasattr(pred.model, "range_fallbacks") else True
+    # the one collective of the path, timed alone (every rank takes part; the profiled extra step below is rank 0 only)
+    all_gather_ms = None
+    if world > 1:
+        tr_l, vi_l = local_step()
+        n_tot = n_gather if c5 else world * N
+        sync()
+        t_ag = time.perf_counter()
+        for _ in range(5):
+            all_gather_tracks(tr_l, vi_l, n_tot)
+        sync()
+        all_gather_ms = (time.perf_counter() - t_ag) / 5 * 1e3
     frames_per_step = pred.step if streaming else T
     if c5:
         total_points = sum(chunk_bounds(N, 8, r)[1] - chunk_bounds(N, 8, r)[0] for r in range(world))
@@ -389,6 +430,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (Linear layers as split-half f16 MFMA x3, f32 accumulate)" if args.precision == "f16x3" else "f32",
         "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": args.dist_backend if world > 1 else None,
+        "all_gather_ms": None if all_gather_ms is None else round(all_gather_ms, 3),
         "config": {"workload": desc, "name": args.workload, "points_per_gpu": n_per_rank, "frames": frames_per_step, "video": [H, W],
                    "iters": 6, "window_len": wl, "offline": bool(offline) and offline != "v2", "sharding": sharding,
                    "precision": args.precision, "weights": "seeded synthetic (no checkpoints offline)"},
@@ -401,7 +444,8 @@ def main():
     # same workload (world == 1, c3_sliding / c2_offline have goldens at exactly these sizes), plus C2 end to end
     if rank == 0:
         parity = {}
-        golden_name = {"c3_sliding": "c3_g80", "c2_offline": "c2"}.get(args.workload)
+        golden_name = {"c3_sliding": "c3_g80", "c2_offline": "c2", "c1_standin": "c1", "c3_offline_g40": "c3_off",
+                       "c5_shard": "c5_chunk0"}.get(args.workload)
         if world == 1 and golden_name and getattr(pred.model, "last_logits", None) is not None:
             vl, cl = pred.model.last_logits
             gp = golden_parity(golden_name, tap["coords"][0], vl[0], cl[0], coords_key="coords")

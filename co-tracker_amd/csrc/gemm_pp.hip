@@ -30,6 +30,12 @@ namespace {
 
 constexpr int PP_HDR_BYTES = 64;
 constexpr int PP_BIAS_BYTES = 8192;  // the whole bias vector (N <= 2048) staged in LDS once per workgroup
+// Every workgroup claims the CU's whole LDS (160 KiB) although it needs 136-152 KiB: with less, a workgroup of ANOTHER
+// kernel (another process sharing the GPU: tests/test_sharding.py runs two ranks on one device) can be placed beside it,
+// this workgroup's LDS then starts at a non-zero base, and the LDS-DMA ring -- whose offsets reach 128 KiB -- went wrong
+// in exactly that situation (first seen as garbage tracks when two processes ran the predictor at the same time; the
+// kernels were bit-exact alone and against each other).  Owning the whole LDS pins the base to 0.
+constexpr int PP_LDS_ALL = 163840;
 
 #define PP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_WAIT_VM(N)                                              \
@@ -45,9 +51,25 @@ constexpr int PP_BIAS_BYTES = 8192;  // the whole bias vector (N <= 2048) staged
 #define PP_BARRIER()                                               \
   do {                                                             \
     PP_SCHED_FENCE();                                              \
+    pp_jitter<DBG>(dbg, wave, jctr);                               \
     __builtin_amdgcn_s_barrier();                                  \
+    pp_jitter<DBG>(dbg, wave, jctr);                               \
     PP_SCHED_FENCE();                                              \
   } while (0)
+
+// experiment (dbg bit 3): pseudo-random per-wave delays at the phase boundaries -- a protocol that is correct must stay
+// bit-exact under any timing
+template <bool DBG>
+__device__ __forceinline__ void pp_jitter(const int dbg, const int wave, unsigned& ctr) {
+  if (DBG && (dbg & 8)) {
+    ctr = ctr * 1664525u + 1013904223u + (unsigned)wave * 2654435761u;
+    const unsigned h = ctr >> 16;
+    if ((h & 3) == 0) {
+      const int n = (h >> 2) & 7;
+      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(20);
+    }
+  }
+}
 
 typedef const __attribute__((address_space(1))) void* pp_gptr;
 typedef __attribute__((address_space(3))) void* pp_lptr;
@@ -248,16 +270,20 @@ __device__ __forceinline__ void pp_cursor_next(const CtkGemmP& g, int tiles_tota
 // every wave has waited for its pieces of blocks <= g + 2 at the end of the load segment of phase g (vmcnt(8): the 4
 // younger blocks stay in flight), one s_barrier before any wave reads them.
 // LDS: A blocks at (J&1)*32K + a*16K, B blocks at 64K + (J&1)*32K + b*16K.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_total, int dbg) {
+template <int EPI, bool DBG>
+__global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
+  const int dbg = DBG ? dbg_arg : 0;  // the experiment knobs exist only in the DBG instantiations
   constexpr int BM = 256, BN = 256;
   constexpr int RING = 131072;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + PP_BIAS_BYTES];  // ONE LDS object (a second one makes hipcc drain vmcnt before ds_reads)
+  // ONE LDS object (a second one makes hipcc drain vmcnt before ds_reads), and ALL 160 KiB of the CU: see PP_LDS_ALL
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS_ALL];
+  static_assert(RING + PP_BIAS_BYTES + 4 * 4096 <= PP_LDS_ALL, "LDS budget");
 
   const int KT = g.K / 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;  // ping-pong group (waves w and w + 4 share a SIMD)
+  unsigned jctr = blockIdx.x * 977u + 1u;
   const int wm = wave >> 2, wn = wave & 3;
   const int r32 = lane & 31, half = lane >> 5;
 
@@ -410,11 +436,14 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
     // ---- epilogue: group 0 after the phase's closing barrier, group 1 before it -- both write their tile at the same
     // time (one MFMA phase apart) and the stagger survives into the next tile
     if (grp == 0) PP_BARRIER();
-    // wave-private 4 KiB for the store transposes: two ring slots are idle here -- B_1 and A_1 of the K-tile just finished
-    // (the next blocks that land there, B_1 / A_1 of K-tile J+2, are issued in phases 0 / 1 of the next K-tile, which each
-    // group enters only after its own epilogue, and the other group only after a barrier behind this epilogue)
+    // wave-private 4 KiB for the store transposes.  Group 0: dedicated space behind the bias.  It must NOT borrow a ring slot:
+    // its waves fall straight from the epilogue into phase 0 of the next K-tile, whose LDS-DMA (B_1 of K-tile J+2) a fast wave
+    // issues while a slow one is still transposing (found by the timing-jitter run of tools/gemm_lab.cpp).  Group 1 borrows
+    // the idle slot A_1 of the K-tile just finished: the next block landing there (A_1 of K-tile J+2) is issued in phase 1,
+    // which no wave enters before a barrier that every group-1 wave reaches only after its epilogue.
     pp_epilogue<EPI, 4, 2>(g, acc, lane, tile.bz, w_unscale, bias_lds,
-                           lds + (grp == 0 ? 65536 : 0) + (par ^ 1) * 32768 + 16384 + (wave & 3) * 4096, row_of, col_of, (dbg & 2) != 0);
+                           grp == 0 ? lds + RING + PP_BIAS_BYTES + wave * 4096 : lds + (par ^ 1) * 32768 + 16384 + (wave & 3) * 4096,
+                           row_of, col_of, (dbg & 2) != 0);
     const bool more = pp_tile<BM, BN>(g, tiles_total, q + 1, tile);
     init_acc();  // unconditional (a conditional re-init doubles the live accumulators at the merge); on the last tile it re-reads valid addresses
     if (grp == 1) PP_BARRIER();
@@ -433,17 +462,20 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
 // block i = 3 J + k is issued in phase i - 4 into the K-tile slot (J & 1) (56 KiB each), where block i - 6 was last read
 // >= 2 phases earlier; waits: end of phase 3J+2 -> I0, I1 of K-tile J+1 (vmcnt(5): I2(J+1) and I0(J+2) stay in flight),
 // end of phase 3J -> I2 of K-tile J (vmcnt(5)), end of phase 3J+1 -> nothing new.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_total, int dbg) {
+template <int EPI, bool DBG>
+__global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
+  const int dbg = DBG ? dbg_arg : 0;
   constexpr int BM = 256, BN = 192;
   constexpr int SLOT = 57344;  // 32 KiB A + 3 x 8 KiB B
   constexpr int RING = 2 * SLOT;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + PP_BIAS_BYTES + 8 * 4096];  // ring | bias | store-transpose scratch
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS_ALL];  // ring | bias | store-transpose scratch (| unused: see PP_LDS_ALL)
+  static_assert(RING + PP_BIAS_BYTES + 8 * 4096 <= PP_LDS_ALL, "LDS budget");
 
   const int KT = g.K / 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
+  unsigned jctr = blockIdx.x * 977u + 1u;
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, half = lane >> 5;
 
@@ -632,10 +664,13 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), blk(512);
   const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
   if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
-#define PP_CASE(E)                                                                                   \
-  case E:                                                                                            \
-    if (t256) hipLaunchKernelGGL((gemm_pp256_kernel<E>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);            \
-    else hipLaunchKernelGGL((gemm_pp192_kernel<E>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);                 \
+  const bool dbgk = (g_pp_mode & ~1) != 0;
+#define PP_CASE(E)                                                                                             \
+  case E:                                                                                                      \
+    if (t256 && dbgk) hipLaunchKernelGGL((gemm_pp256_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);   \
+    else if (t256) hipLaunchKernelGGL((gemm_pp256_kernel<E, false>), grid, blk, 0, s, g, (int)tiles, 0);       \
+    else if (dbgk) hipLaunchKernelGGL((gemm_pp192_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);      \
+    else hipLaunchKernelGGL((gemm_pp192_kernel<E, false>), grid, blk, 0, s, g, (int)tiles, 0);                 \
     break
   switch (code) {
     PP_CASE(pp_epi(CTK_ACT_GELU_ERF, false, true, false, true));    // corr_mlp.fc1

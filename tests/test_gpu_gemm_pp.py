@@ -1,0 +1,85 @@
+"""The persistent ping-pong split-half GEMM kernels (co-tracker_amd/csrc/gemm_pp.hip) through the C-ABI (-m gpu).
+
+Every Linear flavour of the update path, at sizes that take the persistent path (>= one 256-row tile per CU):
+  * against fp64 (the nn.Linear contract) and against gemm_f16x3.hip's kernels (`ctk_gemm_pp_mode(0)`), which run the same
+    MFMA sequence per output element: bit-identical unless the residual is preloaded into the accumulators;
+  * TIMING ROBUSTNESS: `ctk_gemm_pp_mode(9)` makes every wave sleep pseudo-random times around every barrier.  The LDS-DMA
+    ring / barrier protocol must not depend on timing, so the result has to stay bit-identical.  (This is the test that
+    found the round-3 race: a wave leaving its epilogue early issued LDS-DMA into a ring slot another wave of its group
+    was still using as store-transpose scratch -- invisible alone, garbage when a second process shared the GPU.)
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
+# name: (M, K, N, act, residual, SH output, bias rows, bias)
+CASES = {
+    "mlp.fc1": (256 * 47 + 100, 384, 1536, ACT_GELU_TANH, False, True, False, True),    # 256x256 tiles, ragged M
+    "to_kv": (256 * 90, 384, 768, ACT_NONE, False, False, False, True),                 # 256x256
+    "corr_mlp.fc2": (256 * 260, 384, 256, ACT_NONE, False, True, False, True),          # 256x256, one column block
+    "to_q": (256 * 130 + 31, 384, 384, ACT_NONE, False, False, False, True),            # 256x192, ragged M
+    "to_out": (256 * 131, 384, 384, ACT_NONE, True, False, False, True),                # 256x192, residual preload
+    "mlp.fc2": (256 * 129, 1536, 384, ACT_NONE, True, False, False, True),              # 256x192, long K
+    "input_transform": (256 * 140, 1120, 384, ACT_NONE, False, False, True, False),     # 256x192, odd K-tile count (35), bias rows
+    "corr_mlp.fc1": (256 * 128, 2432, 384, ACT_GELU_ERF, False, True, False, True),     # 256x192, erf GELU, SH output
+}
+
+
+def _run(case, mode, data):
+    from cotracker_amd import _lib, ops
+    M, K, N, act, res, split, brows, bias = CASES[case]
+    a_sh, w, wp, b, br, r = data
+    _lib.load().ctk_gemm_pp_mode(mode)
+    try:
+        if res:
+            out = r.clone()
+            ops.gemm(a_sh, w, bias=b, act=act, resid=out, out=out, packed=wp)  # x += Linear(.)
+        else:
+            out = ops.gemm(a_sh, w, bias=b, act=act, bias_rows=br, packed=wp, out_split=split)
+        torch.cuda.synchronize()
+    finally:
+        _lib.load().ctk_gemm_pp_mode(1)
+    return out
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_gemm_pp_matches_fp64_old_kernels_and_survives_timing_jitter(case):
+    from cotracker_amd import ops
+    M, K, N, act, res, split, brows, bias = CASES[case]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(K + N + act)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    br = torch.randn(16, N, generator=g).to(dev) if brows else None
+    r = (3 * torch.randn(M, N, generator=g)).to(dev) if res else None
+    data = (ops.split_rows(a), w, ops.pack_weight(w), b, br, r)
+
+    ref = a.double() @ w.double().t()
+    if bias:
+        ref += b.double()
+    if brows:
+        ref += br.double()[torch.arange(M, device=dev) % 16]
+    if act == ACT_GELU_ERF:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == ACT_GELU_TANH:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    if res:
+        ref += r.double()
+
+    def f32(o):
+        return ops.unsplit(o) if split else o
+
+    old = _run(case, 0, data)
+    new = _run(case, 1, data)
+    tol = 4e-5 * max(1.0, float(ref.abs().max()) / 4)
+    assert float((f32(new).double() - ref).abs().max()) < tol
+    assert float((f32(old).double() - ref).abs().max()) < tol
+    if not res:  # same MFMA sequence per output element
+        assert torch.equal(old, new)
+    for _ in range(3):
+        assert torch.equal(_run(case, 1, data), new), "persistent kernel is not deterministic"
+    for _ in range(3):
+        assert torch.equal(_run(case, 9, data), new), "result depends on wave timing: LDS-DMA / barrier protocol race"

@@ -66,9 +66,18 @@ int main(int argc, char** argv) {
   HIP_OK(hipStreamCreate(&st));
   printf("ctk abi %d\n", ctk_abi_version());
 
+  const bool dense = argc > 1 && (!strcmp(argv[1], "dense") || !strcmp(argv[1], "stress"));  // the shapes of tests/test_sharding.py's dense-mode run (S = 8, 3840 points)
   std::vector<Shape> shapes;
+  if (dense) {
+    shapes.push_back({"fc1  dense    ", 31232, 384, 1536, CTK_ACT_GELU_TANH, false, true, false, true, 1});
+    shapes.push_back({"kv   dense    ", 30720, 384, 768, CTK_ACT_NONE, false, false, false, true, 1});
+    shapes.push_back({"cfc2 dense    ", 30720, 384, 256, CTK_ACT_NONE, false, true, false, true, 4});
+    shapes.push_back({"cfc1 dense    ", 122880, 2432, 384, CTK_ACT_GELU_ERF, false, true, false, true, 1});
+    shapes.push_back({"fc2  dense    ", 31232 * 2, 1536, 384, CTK_ACT_NONE, true, false, false, true, 1});
+  }
   // C3 sliding window (S = 16, N = 6400 points + 64 virtual tracks): rows = 103 424 (tokens) / 102 400 (points)
   const long RT = quick ? 6144 + 100 : 103424, RP = quick ? 6144 : 102400;
+  if (!dense) {
   shapes.push_back({"mlp.fc1       ", RT, 384, 1536, CTK_ACT_GELU_TANH, false, true, false, true, 1});
   shapes.push_back({"mlp.fc2       ", RT, 1536, 384, CTK_ACT_NONE, true, false, false, true, 1});
   shapes.push_back({"to_q          ", RT, 384, 384, CTK_ACT_NONE, false, false, false, true, 1});
@@ -77,7 +86,8 @@ int main(int argc, char** argv) {
   shapes.push_back({"input_transf  ", RP, 1120, 384, CTK_ACT_NONE, false, false, true, false, 1});
   shapes.push_back({"corr_mlp.fc2  ", RP, 384, 256, CTK_ACT_NONE, false, true, false, true, 4});
   shapes.push_back({"corr_mlp.fc1  ", quick ? RP : 4 * RP, 2432, 384, CTK_ACT_GELU_ERF, false, true, false, true, 1});
-  if (!quick) {
+  }
+  if (!quick && !dense) {
     // C2 (offline S = 48, N = 400) and C4 (S = 16, N = 1024) token counts: few tiles per CU
     shapes.push_back({"fc1   @C2     ", 22272, 384, 1536, CTK_ACT_GELU_TANH, false, true, false, true, 1});
     shapes.push_back({"to_out@C2     ", 22272, 384, 384, CTK_ACT_NONE, true, false, false, true, 1});
@@ -191,6 +201,32 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < exp_modes.size(); ++i) printf(" mode %5d: %8.1f us (%.3f) |", exp_modes[i], best[i] * 1e3, 2.0 * M * N * (double)K * B / best[i] / 1e9 / 833.3);
       printf("\n");
       fflush(stdout);
+      HIP_OK(hipFree(dA)); HIP_OK(hipFree(dAsh)); HIP_OK(hipFree(dW)); HIP_OK(hipFree(dC0)); HIP_OK(hipFree(dC1)); HIP_OK(hipFree(dC2));
+      HIP_OK(hipFree(dWp));
+      if (db) HIP_OK(hipFree(db));
+      if (dbr) HIP_OK(hipFree(dbr));
+      continue;
+    }
+    if (argc > 1 && !strcmp(argv[1], "stress")) {  // repeated runs of one mode, every output compared bitwise with the first
+      const int mode = argc > 2 ? atoi(argv[2]) : 1, iters = argc > 3 ? atoi(argv[3]) : 200;
+      std::vector<float> ref((size_t)c_elems), cur((size_t)c_elems);
+      int bad = 0;
+      const int burst = argc > 4 ? atoi(argv[4]) : 1;  // launches per synchronisation (back-to-back on the stream)
+      for (int it = 0; it < iters; ++it) {
+        for (int b = 0; b < (it ? burst : 1); ++b) run(dC1, mode);
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpy(it ? cur.data() : ref.data(), dC1, c_elems * 4, hipMemcpyDeviceToHost));
+        if (it && memcmp(ref.data(), cur.data(), c_elems * 4)) {
+          long nbad = 0, first = -1;
+          for (long i = 0; i < c_elems; ++i)
+            if (memcmp(&ref[i], &cur[i], 4)) { if (first < 0) first = i; ++nbad; }
+          if (bad < 5) printf("  iter %d: %ld words differ, first at row %ld col %ld\n", it, nbad, first / ldc, first % ldc);
+          ++bad;
+        }
+      }
+      printf("%s mode %d: %d of %d runs differ from the first\n", sh.name, mode, bad, iters - 1);
+      fflush(stdout);
+      failures += bad != 0;
       HIP_OK(hipFree(dA)); HIP_OK(hipFree(dAsh)); HIP_OK(hipFree(dW)); HIP_OK(hipFree(dC0)); HIP_OK(hipFree(dC1)); HIP_OK(hipFree(dC2));
       HIP_OK(hipFree(dWp));
       if (db) HIP_OK(hipFree(db));

@@ -1,0 +1,61 @@
+#!/bin/bash
+# Round-3 GPU session: tools/gpu_session_r03.sh [tests] [bench] [more] [prof] [pmc] [lab]
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+WHAT="${*:-tests bench}"
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+summ() {  # summ <tag> <json>
+  python - "$1" "$2" <<'PY'
+import json, sys
+tag, f = sys.argv[1:3]
+try:
+    d = json.load(open(f))
+    print(tag, d["value"], d["ms_per_step"], "ms; parity:", json.dumps(d.get("parity"))[:700])
+    if tag == "c3":
+        for k in d.get("kernels", [])[:26]: print("   ", k)
+        for key in ("roofline", "roofline_gemm", "roofline_sampler", "cpu_baseline"):
+            print(key, {k: v for k, v in (d.get(key) or {}).items() if k not in ("note", "traffic_detail", "traffic_note", "reference_in_build_container", "sample")})
+except Exception as e:
+    print(tag, "parse failed", e)
+    try: print(open(f.replace(".json", ".err")).read()[-3000:])
+    except Exception: pass
+PY
+}
+if has lab; then
+  (timeout 600 tools/gemm_lab 2>&1 | tail -20) | tee gpurun_out/r03_gemm_lab.log
+fi
+if has tests; then
+  (timeout 2400 python -m pytest tests -m gpu -q -x --durations=8 2>&1 | tail -40) > gpurun_out/r03_pytest_gpu.log
+  tail -22 gpurun_out/r03_pytest_gpu.log
+fi
+if has bench; then
+  (timeout 900 python bench.py --steps 3 --warmup 1 2>gpurun_out/r03_bench_c3.err | tail -1) > gpurun_out/r03_bench_c3.json
+  summ c3 gpurun_out/r03_bench_c3.json
+fi
+if has more; then
+  for w in c2_offline c4_online c5_shard c3_offline c3_offline_g40 c1_standin v2_sliding; do
+    st=3; [[ $w == c4_online ]] && st=12; [[ $w == c5_shard || $w == c3_offline* || $w == v2_sliding ]] && st=2
+    (timeout 600 python bench.py --workload $w --steps $st --warmup 1 --no-cpu-baseline 2>gpurun_out/r03_bench_$w.err | tail -1) > gpurun_out/r03_bench_$w.json
+    summ $w gpurun_out/r03_bench_$w.json
+  done
+  (timeout 600 python bench.py --precision f32 --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/r03_bench_c3_f32.err | tail -1) > gpurun_out/r03_bench_c3_f32.json
+  summ c3_f32 gpurun_out/r03_bench_c3_f32.json
+  (timeout 900 python bench.py --gpus 2 --single-device --dist-backend gloo --workload tiny --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/r03_bench_2rank.err | tail -1) > gpurun_out/r03_bench_2rank_gloo_single_device_tiny.json
+  summ 2rank gpurun_out/r03_bench_2rank_gloo_single_device_tiny.json
+fi
+if has prof; then
+  cd /tmp && rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats -d /tmp/prof -o r03 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /tmp/prof_bench.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
+  python tools/summarize_rocprof.py "$f" > gpurun_out/r03_rocprof_kernel_stats.txt 2>&1 || cp "$f" gpurun_out/r03_rocprof_kernel_stats.csv
+  head -30 gpurun_out/r03_rocprof_kernel_stats.txt
+fi
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    cd /tmp && rm -rf /tmp/pmc_$c && rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o r03 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /tmp/pmc_$c.log 2>&1
+    cd $GRAFT_REPO_ROOT
+  done
+  python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > gpurun_out/r03_pmc_traffic.txt 2>&1
+  cp profiles/pmc_traffic.json gpurun_out/r03_pmc_traffic.json 2>/dev/null
+  tail -30 gpurun_out/r03_pmc_traffic.txt
+fi
