@@ -102,8 +102,9 @@ __device__ __forceinline__ void pp_epilogue(const CtkGemmP& g, f32x16 (&acc)[MI]
   constexpr int ACT = EPI & 3;
   constexpr bool SPLIT = (EPI & 8) != 0, BROWS = (EPI & 16) != 0, BIAS = (EPI & 32) != 0;
   const int r32 = lane & 31, half = lane >> 5;
+  constexpr bool BV_REGS = (EPI & 4) == 0;  // residual kernels hold the next tile's residual in registers here: bias straight from LDS
   f32x4 bv[NI][4];
-  if (BIAS) {
+  if (BIAS && BV_REGS) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -142,7 +143,7 @@ __device__ __forceinline__ void pp_epilogue(const CtkGemmP& g, f32x16 (&acc)[MI]
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][q * 4 + e] * unscale;
-        if (BIAS) v += bv[ni][q];
+        if (BIAS) v += BV_REGS ? bv[ni][q] : *reinterpret_cast<const f32x4*>(bias_lds + col_of(ni) + q * 8 + half * 4);
         if (BROWS) v += *reinterpret_cast<const f32x4*>(bp + col_of(ni) + q * 8);
         if (ACT == CTK_ACT_GELU_ERF) {
 #pragma unroll
@@ -180,25 +181,62 @@ __device__ __forceinline__ void pp_stage_bias(const CtkGemmP& g, unsigned char* 
 }
 
 // Accumulator start values of a tile: 0, or (EPI bit 2) the residual tile times the weight scale s -- the epilogue's
-// "* 1/s" then returns it exactly (s is a power of two) and the loads have the whole main loop to land.
+// "* 1/s" then returns it exactly (s is a power of two).  Like the stores, the residual is moved in full 128-byte lines
+// (4 dwordx4 loads of 8 rows each per 32x32 sub-tile, all sub-tiles requested before the first is used) and transposed to
+// the accumulator layout through the wave's 4 KiB LDS image: fetched in that layout directly (32 rows x 32 B per
+// instruction) the preload cost as much as the stores did (to_out 154 us against 115 us for the same Linear without it).
+template <int MI, int NI>
+struct PPResid {
+  f32x4 line[MI][NI][4];
+};
+
+// issue the residual loads of a tile (rows / columns given by row_of / col_of); nothing waits for them here
 template <int EPI, int MI, int NI, class RowOf, class ColOf>
-__device__ __forceinline__ void pp_init_acc(const CtkGemmP& g, f32x16 (&acc)[MI][NI], const int r32, const int half, const int bz,
-                                            const float scale, RowOf row_of, ColOf col_of) {
-  constexpr bool RES = (EPI & 4) != 0;
+__device__ __forceinline__ void pp_resid_issue(const CtkGemmP& g, PPResid<MI, NI>& r, const int lane, const int bz, RowOf row_of, ColOf col_of) {
+  if ((EPI & 4) == 0) return;
+  const int rrow = lane >> 3, rchunk = lane & 7;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int rowc = min(row_of(mi) + r32, g.M - 1);
-    const float* rp = RES ? g.resid + (long)bz * g.c_bs + (long)rowc * g.ldr + half * 4 : nullptr;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int i = 0; i < 4; ++i) {
+      const int rowc = min(row_of(mi) + rrow + 8 * i, g.M - 1);
+      const float* rp = g.resid + (long)bz * g.c_bs + (long)rowc * g.ldr + rchunk * 4;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) r.line[mi][ni][i] = *reinterpret_cast<const f32x4*>(rp + col_of(ni));
+    }
+  }
+}
+
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void pp_init_acc(f32x16 (&acc)[MI][NI], const PPResid<MI, NI>& r, const int lane, const float scale, unsigned char* scratch) {
+  constexpr bool RES = (EPI & 4) != 0;
+  if (!RES) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+    return;
+  }
+  const int r32 = lane & 31, half = lane >> 5;
+  const int rrow = lane >> 3, rchunk = lane & 7;
+  unsigned char* wr = scratch + rrow * 128 + ((rchunk ^ rrow) << 4);  // row r = rrow + 8 i, chunk c at position c ^ (r & 7)
+  const unsigned char* rd = scratch + r32 * 128;
+  const int rsw = r32 & 7;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(wr + i * 1024) = r.line[mi][ni][i] * scale;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (RES) v = *reinterpret_cast<const f32x4*>(rp + col_of(ni) + q * 8) * scale;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rd + (((2 * q + half) ^ rsw) << 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mi][ni][q * 4 + e] = v[e];
       }
-  }
+    }
 }
 
 // ---- tile walk -----------------------------------------------------------------------------------
@@ -349,9 +387,19 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   };
 
   f32x16 acc[4][2];  // [a*2 + mi][b]
+  int par = 0;  // parity of the K-tile being computed
   auto row_of = [&](int i) { return tile.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; };
   auto col_of = [&](int b) { return tile.n0 + wn * 32 + b * 128; };
-  auto init_acc = [&]() { pp_init_acc<EPI, 4, 2>(g, acc, r32, half, tile.bz, w_scale, row_of, col_of); };
+  // wave-private 4 KiB for the store / residual transposes.  Group 0: dedicated space behind the bias.  It must NOT borrow a
+  // ring slot: its waves fall straight from the epilogue into phase 0 of the next K-tile, whose LDS-DMA (B_1 of K-tile J+2) a
+  // fast wave issues while a slow one is still transposing (found by the timing-jitter run of tools/gemm_lab.cpp).  Group 1
+  // borrows the idle slot A_1 of the K-tile just finished (parity par ^ 1 once par has advanced): the next block landing
+  // there (A_1 of K-tile J+2) is issued in phase 1, which no wave enters before a barrier that every group-1 wave reaches
+  // only after its epilogue and accumulator set-up.
+  auto scratch = [&]() { return grp == 0 ? lds + RING + PP_BIAS_BYTES + wave * 4096 : lds + (par ^ 1) * 32768 + 16384 + (wave & 3) * 4096; };
+  PPResid<4, 2> resid;
+  auto resid_issue = [&]() { pp_resid_issue<EPI, 4, 2>(g, resid, lane, tile.bz, row_of, col_of); };
+  auto init_acc = [&]() { pp_init_acc<EPI, 4, 2>(acc, resid, lane, w_scale, scratch()); };
   // operands swapped on purpose (D'[n][m]: lane = output row, register quad = 4 consecutive columns); small terms first
   auto mma = [&](const int a, const int b) {
     __builtin_amdgcn_s_setprio(1);
@@ -381,12 +429,12 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
     c2 = c1;
     pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
   }
+  resid_issue();
   init_acc();
   PP_WAIT_VM(8);   // blocks 0, 1 (K-tile 0: A_0, B_0) have landed
   PP_BARRIER();
   if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one barrier behind group 0
 
-  int par = 0;
   for (int q = 0;; ++q) {  // my tiles
     for (int kt = 0; kt < KT; ++kt) {
       // ---- phase 0 (a=0, b=0): read A_0, B_0; issue B_1 of K-tile J+1
@@ -436,16 +484,15 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
     // ---- epilogue: group 0 after the phase's closing barrier, group 1 before it -- both write their tile at the same
     // time (one MFMA phase apart) and the stagger survives into the next tile
     if (grp == 0) PP_BARRIER();
-    // wave-private 4 KiB for the store transposes.  Group 0: dedicated space behind the bias.  It must NOT borrow a ring slot:
-    // its waves fall straight from the epilogue into phase 0 of the next K-tile, whose LDS-DMA (B_1 of K-tile J+2) a fast wave
-    // issues while a slow one is still transposing (found by the timing-jitter run of tools/gemm_lab.cpp).  Group 1 borrows
-    // the idle slot A_1 of the K-tile just finished: the next block landing there (A_1 of K-tile J+2) is issued in phase 1,
-    // which no wave enters before a barrier that every group-1 wave reaches only after its epilogue.
-    pp_epilogue<EPI, 4, 2>(g, acc, lane, tile.bz, w_unscale, bias_lds,
-                           grp == 0 ? lds + RING + PP_BIAS_BYTES + wave * 4096 : lds + (par ^ 1) * 32768 + 16384 + (wave & 3) * 4096,
-                           row_of, col_of, (dbg & 2) != 0);
+    // the next tile's residual is requested BEFORE this tile's epilogue (it lands behind the epilogue's arithmetic and stores);
+    // the epilogue therefore works on a copy of the tile descriptor
+    const PPTile done = tile;
     const bool more = pp_tile<BM, BN>(g, tiles_total, q + 1, tile);
-    init_acc();  // unconditional (a conditional re-init doubles the live accumulators at the merge); on the last tile it re-reads valid addresses
+    resid_issue();  // unconditional (on the last tile it re-reads valid addresses; a conditional re-init doubles the live accumulators)
+    pp_epilogue<EPI, 4, 2>(g, acc, lane, done.bz, w_unscale, bias_lds, scratch(),
+                           [&](int i) { return done.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; }, [&](int b) { return done.n0 + wn * 32 + b * 128; },
+                           (dbg & 2) != 0);
+    init_acc();
     if (grp == 1) PP_BARRIER();
     if (!more) break;
   }
@@ -555,7 +602,9 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   f32x16 acc[2][3];
   auto row_of = [&](int mi) { return tile.m0 + wm * 64 + mi * 32; };
   auto col_of = [&](int ni) { return tile.n0 + wn * 32 + ni * 64; };
-  auto init_acc = [&]() { pp_init_acc<EPI, 2, 3>(g, acc, r32, half, tile.bz, w_scale, row_of, col_of); };
+  PPResid<2, 3> resid;
+  auto resid_issue = [&]() { pp_resid_issue<EPI, 2, 3>(g, resid, lane, tile.bz, row_of, col_of); };
+  auto init_acc = [&]() { pp_init_acc<EPI, 2, 3>(acc, resid, lane, w_scale, lds + RING + PP_BIAS_BYTES + wave * 4096); };
   auto mma = [&](const int n) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -581,6 +630,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     c2 = c1;
     pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
   }
+  resid_issue();
   init_acc();
   set_rd(0);
   PP_WAIT_VM(5);  // I0, I1 of K-tile 0 landed (I2: 2 pieces and I0 of K-tile 1: 3 pieces may be in flight)
@@ -621,9 +671,12 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
       set_rd(par);
     }
     if (grp == 0) PP_BARRIER();
-    pp_epilogue<EPI, 2, 3>(g, acc, lane, tile.bz, w_unscale, bias_lds, lds + RING + PP_BIAS_BYTES + wave * 4096, row_of, col_of, (dbg & 2) != 0);
+    const PPTile done = tile;
     const bool more = pp_tile<BM, BN>(g, tiles_total, q + 1, tile);
-    init_acc();  // unconditional (a conditional re-init doubles the live accumulators at the merge); on the last tile it re-reads valid addresses
+    resid_issue();  // next tile's residual, requested before this tile's epilogue (see gemm_pp256_kernel)
+    pp_epilogue<EPI, 2, 3>(g, acc, lane, done.bz, w_unscale, bias_lds, lds + RING + PP_BIAS_BYTES + wave * 4096,
+                           [&](int mi) { return done.m0 + wm * 64 + mi * 32; }, [&](int ni) { return done.n0 + wn * 32 + ni * 64; }, (dbg & 2) != 0);
+    init_acc();
     if (grp == 1) PP_BARRIER();
     if (!more) break;
   }
