@@ -457,6 +457,85 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
   else gemm_epilogue_c<MR, NR, EPI>(g, acc, m0 + wm * 32 * MR, n0 + wn * 32 * NR, r32, half, bz);
 }
 
+// ---- deep-pipeline 64 x 64 kernel for the small-M Linears (the 64 virtual tracks: M = 64 S rows) ------------------
+// gemm_sh_kernel<2,2,1,1,2> spends a whole LDS-DMA latency per K-tile there when its operands are cold (6 MFMAs per wave
+// and K-tile cannot hide an L2 miss behind two stages).  Same tile and fragment layout, but NS stages of 16 KiB: NS - 1
+// K-tiles are always in flight behind a counted vmcnt, one raw barrier per K-tile.
+template <int NS>
+__global__ __launch_bounds__(256) void gemm_sh_deep64_kernel(CtkGemmP g) {
+  constexpr int BM = 64, BN = 64, STAGE = (BM + BN) * 128, GPW = 4;  // 16 pieces of 8 rows per K-tile, 4 per wave
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
+  unsigned tile = ctk_xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = tile % g.nblocks;
+  tile /= g.nblocks;
+  const int mb = tile % g.mblocks;
+  const int bz = tile / g.mblocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+  const int KT = g.K / BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  const _Float16* Ash = static_cast<const _Float16*>(g.A) + (long)bz * g.a_bs;
+  const _Float16* Wsh = reinterpret_cast<const _Float16*>(g.Wp) + HDR_BYTES / 2;
+  const _Float16* src[GPW];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int lrow = (i * 4 + wave) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
+    if (lrow < BM) src[i] = Ash + (long)min(m0 + lrow, g.M - 1) * g.lda + chunk * 8;
+    else src[i] = Wsh + (long)(n0 + lrow - BM) * KT * 64 + chunk * 8;
+  }
+  auto dma = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < GPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)kt * 64),
+                                       (__attribute__((address_space(3))) void*)(lds + stage * STAGE + (i * 4 + wave) * 1024), 16, 0, 0);
+  };
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+  const int fsw = (r32 >> 1) & 7;
+  const int a_row = (wm * 32 + r32) * 128, w_row = (BM + wn * 32 + r32) * 128;
+  int coff[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) coff[j][p] = ((p * 4 + j * 2 + half) ^ fsw) << 4;
+
+  // prologue: NS - 1 K-tiles requested (short K: the missing ones are re-requests of the last tile, so the counts stay uniform)
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) dma(min(i, KT - 1), i);
+  int st = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    // K-tile kt has landed (mine: all but the NS - 2 younger requests are complete), then everyone's (barrier)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the stage of K-tile kt - 1 is free now (every wave has consumed its fragments before reaching this barrier)
+    dma(min(kt + NS - 1, KT - 1), st == 0 ? NS - 1 : st - 1);
+    const unsigned char* sp = lds + st * STAGE;
+    f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      ah[j] = *reinterpret_cast<const f16x8*>(sp + a_row + coff[j][0]);
+      al[j] = *reinterpret_cast<const f16x8*>(sp + a_row + coff[j][1]);
+      wh[j] = *reinterpret_cast<const f16x8*>(sp + w_row + coff[j][0]);
+      wl[j] = *reinterpret_cast<const f16x8*>(sp + w_row + coff[j][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // operands swapped, small terms first (as gemm_sh_kernel)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[j], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[j], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[j], acc[0][0], 0, 0, 0);
+    }
+    st = (st + 1 == NS) ? 0 : st + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the duplicate tail requests
+  gemm_epilogue<1, 1>(g, acc, m0 + wm * 32, n0 + wn * 32, r32, half, bz);
+}
+
 // A persistent variant (resident workgroups walking over the tiles, the next tile's first two K-tiles prefetched by DMA
 // across the epilogue) was built and measured in round 2 and REMOVED: identical times (q/out shape 151.2 vs 152.4 us,
 // K >= 768 slightly slower; profiles/r02_gemm_persistent_ab.txt).  The per-tile cost that tools/bench_gemm_sweep.py
@@ -648,7 +727,10 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
     } else {
       g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
       CtkProfScope ps(prof_name("64"), flops, bytes, s);
-      hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
+      static const int deep = [] { const char* e = getenv("CTK_GEMM_DEEP64"); return e ? atoi(e) : 4; }();  // dev knob, read once: 0 = 2-stage kernel, 4 / 8 = stages
+      if (deep >= 8) hipLaunchKernelGGL((gemm_sh_deep64_kernel<8>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
+      else if (deep >= 4) hipLaunchKernelGGL((gemm_sh_deep64_kernel<4>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
     }
   } else if (big) {
     g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;

@@ -87,7 +87,15 @@ int main(int argc, char** argv) {
   shapes.push_back({"corr_mlp.fc2  ", RP, 384, 256, CTK_ACT_NONE, false, true, false, true, 4});
   shapes.push_back({"corr_mlp.fc1  ", quick ? RP : 4 * RP, 2432, 384, CTK_ACT_GELU_ERF, false, true, false, true, 1});
   }
-  if (!quick && !dense) {
+  if (argc > 1 && !strcmp(argv[1], "small")) {  // the virtual-track Linears (64 x S rows): 64 x 64 tile kernels
+    shapes.clear();
+    shapes.push_back({"v.q/out       ", 1024, 384, 384, CTK_ACT_NONE, true, false, false, true, 1});
+    shapes.push_back({"v.kv          ", 1024, 384, 768, CTK_ACT_NONE, false, false, false, true, 1});
+    shapes.push_back({"v.fc1         ", 1024, 384, 1536, CTK_ACT_GELU_TANH, false, true, false, true, 1});
+    shapes.push_back({"v.fc2         ", 1024, 1536, 384, CTK_ACT_NONE, true, false, false, true, 1});
+    shapes.push_back({"v.q S=120     ", 7680, 384, 384, CTK_ACT_NONE, true, false, false, true, 1});
+  }
+  if (!quick && !dense && !(argc > 1 && !strcmp(argv[1], "small"))) {
     // C2 (offline S = 48, N = 400) and C4 (S = 16, N = 1024) token counts: few tiles per CU
     shapes.push_back({"fc1   @C2     ", 22272, 384, 1536, CTK_ACT_GELU_TANH, false, true, false, true, 1});
     shapes.push_back({"to_out@C2     ", 22272, 384, 384, CTK_ACT_NONE, true, false, false, true, 1});
