@@ -299,6 +299,8 @@ def main():
         from cotracker_amd.predictor import CoTrackerOnlinePredictor
         pred = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
         pred.model.hip_graph = not args.no_graph
+        # the workload's chunks overlap by window_len - step frames (predictor.py:288-290): opt in to re-using their features
+        pred.model.online_feature_cache = True
         T = pred.step * (args.steps + args.warmup + 3)  # one chunk call per step, plus the profiled call
     elif offline == "v2":
         pred = CoTrackerPredictor(checkpoint=None, v2=True, window_len=wl)
@@ -438,6 +440,7 @@ def main():
     }
     if streaming:
         result["config"]["hip_graph"] = bool(pred.model.hip_graph)
+        result["config"]["online_feature_cache"] = bool(pred.model.online_feature_cache)
         result["config"]["graph_nodes"] = next(iter(pred.model._graphs.values())).nodes if pred.model._graphs else 0
 
     # parity of what was just timed: the last timed step's model-level outputs against the reference's CPU run of the

@@ -19,7 +19,7 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -39,6 +39,9 @@ class ModelWeights(C.Structure):
     ]
 
 
+WINDOW_NO_SPACE_ATTN = 1  # ctk_window_args.flags
+
+
 class WindowArgs(C.Structure):
     _fields_ = [
         ("S", C.c_int32), ("N", C.c_int32), ("iters", C.c_int32),
@@ -49,6 +52,7 @@ class WindowArgs(C.Structure):
         ("scale_x", C.c_float), ("scale_y", C.c_float),
         ("points_per_chunk", C.c_int32),
         ("aux_stream", _fp),
+        ("flags", C.c_int32),
     ]
 
 

@@ -32,31 +32,48 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // The events are host objects created on first use and kept for the life of the process (the second exception, after
 // the profiler, to "no mutable global state"); both calls are legal during stream capture, where they become graph edges
 // and pull the auxiliary stream into the capture.
+// One ring per device (an event belongs to the device that was current when it was created: recording it on another
+// device's stream is an invalid-handle error), creation errors are reported to the caller.
 class EventRing {
  public:
-  hipEvent_t next() {
+  int next(hipEvent_t* out) {
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return (int)rc;
+    if (dev < 0 || dev >= kMaxDev) return CTK_E_STATE;
     std::lock_guard<std::mutex> g(m_);
-    if (!ready_) {
-      for (auto& e : ev_) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-      ready_ = true;
+    PerDev& d = d_[dev];
+    if (!d.ready) {
+      for (int i = 0; i < kN; ++i) {
+        rc = hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming);
+        if (rc != hipSuccess) {
+          for (int j = 0; j < i; ++j) (void)hipEventDestroy(d.ev[j]);
+          return (int)rc;
+        }
+      }
+      d.ready = true;
     }
-    hipEvent_t e = ev_[i_];
-    i_ = (i_ + 1) % kN;
-    return e;
+    *out = d.ev[d.i];
+    d.i = (d.i + 1) % kN;
+    return CTK_OK;
   }
 
  private:
-  static constexpr int kN = 256;
+  static constexpr int kN = 256, kMaxDev = 64;
+  struct PerDev {
+    hipEvent_t ev[kN];
+    int i = 0;
+    bool ready = false;
+  };
   std::mutex m_;
-  hipEvent_t ev_[kN];
-  int i_ = 0;
-  bool ready_ = false;
+  PerDev d_[kMaxDev];
 };
 EventRing g_events;
 
 // `to` waits for everything enqueued on `from` so far
 int stream_follow(hipStream_t from, hipStream_t to) {
-  hipEvent_t e = g_events.next();
+  hipEvent_t e;
+  CTK_TRY(g_events.next(&e));
   hipError_t rc = hipEventRecord(e, from);
   if (rc != hipSuccess) return (int)rc;
   rc = hipStreamWaitEvent(to, e, 0);
@@ -70,10 +87,29 @@ int stream_follow(hipStream_t from, hipStream_t to) {
 // 1.21 ms, fc1 2.24 -> 4 x 0.77 ms per iteration; step 1528.5 -> 1547.3 ms) -- and the side query projection is worth
 // 0.15 % (1526.1 ms), inside run-to-run noise.  Results are bit-identical in every mode (tests), so the code stays
 // as an opt-in for other shapes.
-int overlap_mode() {
-  const char* e = getenv("CTK_OVERLAP");
-  return e ? atoi(e) : 0;
+int overlap_mode() {  // dev knob, read ONCE (getenv on the enqueue path races with setenv in multithreaded hosts)
+  static const int mode = [] { const char* e = getenv("CTK_OVERLAP"); return e ? atoi(e) : 0; }();
+  return mode;
 }
+
+// Joins `aux` back into `main` when a fork is still open at scope exit (an error return between fork and join would
+// otherwise leave the auxiliary stream unjoined -- inside ctk_window_graph_create: stuck in a broken capture).
+struct JoinGuard {
+  hipStream_t main, aux;
+  bool open = false;
+  int fork() {
+    const int rc = stream_follow(main, aux);
+    open = rc == CTK_OK;
+    return rc;
+  }
+  int join() {
+    open = false;
+    return stream_follow(aux, main);
+  }
+  ~JoinGuard() {
+    if (open) (void)stream_follow(aux, main);
+  }
+};
 
 // A Linear's weight: torch-layout f32 and/or the ctk_pack_weight blob (preferred when present).
 struct WRef {
@@ -183,6 +219,7 @@ struct FormerRef {
   const uint8_t* point_mask;  // CoTracker2 attention_mask per point (cotracker.py:343-345) or null
   bool split;                 // xn / att / hid are SH-format (split-half back end)
   hipStream_t aux;            // optional second stream (ctk_window_args.aux_stream) or null
+  bool space_attn = true;     // false: add_space_attn=False (cotracker.py:496-502): the three space blocks are skipped
 };
 
 FormerRef former_of(const ctk_model_weights* w) {
@@ -220,10 +257,12 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     // time block just produced, not on the virtual tracks: with an auxiliary stream it runs BESIDE the virtual-track
     // chain below (virtual<-points attention, two 1024-row MLPs, virtual self attention: ~16 launches that occupy a
     // fraction of the chip), into its own xn2 buffer and the (otherwise unused) q columns of the point rows of qkv.
+    if (!fr.space_attn) continue;
     const bool side_q = fr.aux != nullptr && (overlap_mode() & 2) != 0;
+    JoinGuard side{s, fr.aux};
     if (side_q) {
       const ctk_block_weights& b = w->point2virtual[i];
-      CTK_TRY(stream_follow(s, fr.aux));
+      CTK_TRY(side.fork());
       CTK_TRY(ctk_layernorm(tok, ws.xn2, P, nullptr, nullptr, 1e-6f, sp, fr.aux));                                          // norm1(points)
       CTK_TRY(gemm(ws.xn2, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, fr.aux, nullptr, 0, 1, 0, 0, 0, sp, false));
     }
@@ -259,7 +298,7 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
       if (!side_q) CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, sp, s));                                 // norm1(points)
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));           // norm_context(virtual)
       if (!side_q) CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
-      else CTK_TRY(stream_follow(fr.aux, s));  // join: q(points) is ready
+      else CTK_TRY(side.join());  // join: q(points) is ready
       CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s, sp,
                    nullptr, fr.point_mask));  // mask over QUERIES (cotracker.py:561-564)
@@ -352,6 +391,7 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
     // fits on a CU (77 KiB + 64 KiB of LDS).  Each piece has its own slice of the volume / hidden buffers.
     const int pieces = pipelined ? ((cnt >= 4096) ? 4 : (cnt >= 1024 ? 2 : 1)) : 1;
     const int per = (cnt + pieces - 1) / pieces;
+    JoinGuard pipe{s, aux};
     for (int j = 0; j < pieces; ++j) {
       const int p0 = j * per;
       const int pc = (cnt - p0 < per) ? cnt - p0 : per;
@@ -363,7 +403,7 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
       if (sp) CTK_TRY(ctk_launch_corr_volume_sh(a, ws.fm_sh, n0 + p0, pc, vol, rows * CTK_CORR_LD * 2, s));
       else CTK_TRY(ctk_launch_corr_volume(a, n0 + p0, pc, vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
       if (pipelined && pieces > 1) {
-        CTK_TRY(stream_follow(s, aux));
+        CTK_TRY(pipe.fork());
         gs = aux;
       }
       // corr_mlp.fc1 + exact GELU over all 4 levels at once        cotracker3_online.py:205, blocks.py:71-72
@@ -373,7 +413,7 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
       CTK_TRY(gemm(h1, CTK_HID, (int)rows, WRef{w->corr_fc2_w, w->corr_fc2_p}, CTK_HID, 256, CTK_HID, x + (long)(n0 + p0) * a->S * CTK_X_LD + CTK_X_CORR,
                    CTK_X_LD, w->corr_fc2_b, CTK_ACT_NONE, nullptr, 0, gs, nullptr, 0, CTK_LEVELS, rows * CTK_HID, 256, 0, sp, x_split));
     }
-    if (pipelined && pieces > 1) CTK_TRY(stream_follow(aux, s));  // join before the next chunk reuses the buffers / x is consumed
+    if (pipelined && pieces > 1) CTK_TRY(pipe.join());  // join before the next chunk reuses the buffers / x is consumed
   }
   return CTK_OK;
 }
@@ -522,6 +562,7 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
     CTK_TRY(input_projection(a->S, a->N, x, sp, w, uws, s));    // :247 + cotracker.py:484
     FormerRef fr = former_of(w);
     fr.aux = static_cast<hipStream_t>(a->aux_stream);
+    fr.space_attn = (a->flags & CTK_WINDOW_NO_SPACE_ATTN) == 0;
     CTK_TRY(run_transformer(a->S, a->N, fr, uws, s));           // :250
     CTK_TRY(ctk_launch_heads(uws.tokens, w->head_w, w->head_b, a->S, a->N, nullptr, a->coords, a->vis, a->conf, s));  // :252-259
   }

@@ -898,8 +898,8 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
     p.qtiles = p.bpw == 2 ? 1 : (a->n1 + 31) / 32;
     const long njobs = (long)((a->nbatch + p.bpw - 1) / p.bpw) * p.qtiles;
     CtkProfScope ps(a->q_is == 1 ? "attention_time" : "attention_vself", flops, bytes, s);
-    const char* tk = getenv("CTK_ATTN_TIME");  // dev knob: 0 = the non-persistent kernel
-    if (p.bpw == 2 && !p.kmask && !p.qmask && !(tk && atoi(tk) == 0)) {
+    static const bool persistent = [] { const char* tk = getenv("CTK_ATTN_TIME"); return !(tk && atoi(tk) == 0); }();  // dev knob, read once: 0 = the non-persistent kernel
+    if (p.bpw == 2 && !p.kmask && !p.qmask && persistent) {
       // persistent waves: 2 workgroups per CU, each wave walks over ~njobs*8/2048 (batch pair, head) jobs
       const long total = njobs * CTK_HEADS;
       const unsigned blocks = (unsigned)((total + 3) / 4 < 512 ? (total + 3) / 4 : 512);

@@ -693,7 +693,7 @@ int pp_num_cus() {
   return n;
 }
 
-int g_pp_mode = 1;  // bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; experiments: bit 1 = no stores, bits 8.. = start stagger
+int g_pp_mode = [] { const char* e = getenv("CTK_GEMM_PP"); return e ? atoi(e) : 1; }();  // (env: initial value, read once) bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; experiments: bit 1 = no stores, bits 8.. = start stagger
 
 }  // namespace
 

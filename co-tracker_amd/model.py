@@ -242,8 +242,10 @@ class CoTrackerThreeBase(nn.Module):
         self.range_guard = True
         self.range_fallbacks = 0
         self.encoder_dtype = torch.float32  # fp32 as the reference; see tools/probe_encoder_precision.py for why not lower
-        # streaming: reuse the previous chunk's features for the overlapping frames (see _encode_online); not a reference kwarg
-        self.online_feature_cache = True
+        # streaming: reuse the previous chunk's features for the overlapping frames (see _encode_online).  Not a reference
+        # kwarg and OFF by default (the reference re-encodes whatever chunk it is given, predictor.py:288-290); opt in for
+        # streams whose chunks overlap by window_len - step frames (bench.py's configs[3] workload does)
+        self.online_feature_cache = False
         self.encoder_chunk = 16  # frames per CNN call (see _encode); not a reference kwarg
         # pre-sigmoid (visibility, confidence) of the last forward, [B,T,N] each -- parity tests compare logits
         self.last_logits = None
@@ -278,10 +280,15 @@ class CoTrackerThreeBase(nn.Module):
             self._graphs = {}
 
     # device-side caches (ctypes structs with raw pointers) are rebuilt on demand: keep them out of pickles / deep copies
+    _TRANSIENT = {"_packed": dict, "_graphs": dict, "_pending_range": type(None), "_pending_overlap": type(None),
+                  "online_f0_tail": type(None), "_online_prev_frames": type(None)}
+
     def __getstate__(self):
+        self._resolve_deferred_range_check()  # a pending (pinned flag, cuda Event) pair cannot be pickled, and must not be lost
         st = self.__dict__.copy()
-        st["_packed"] = {}
-        st["_graphs"] = {}
+        for k, mk in self._TRANSIENT.items():
+            if k in st:
+                st[k] = mk()
         return st
 
     def __deepcopy__(self, memo):
@@ -289,8 +296,9 @@ class CoTrackerThreeBase(nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
+        self._resolve_deferred_range_check()
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k in ("_packed", "_graphs") else copy.deepcopy(v, memo)
+            new.__dict__[k] = self._TRANSIENT[k]() if k in self._TRANSIENT else copy.deepcopy(v, memo)
         return new
 
     def _guarded(self, run, snapshot=None, restore=None, deferred=False):
@@ -321,15 +329,6 @@ class CoTrackerThreeBase(nn.Module):
         return out
 
     def _resolve_deferred_range_check(self):
-        pending, self._pending_overlap = getattr(self, "_pending_overlap", None), None
-        if pending is not None:
-            flag, ev = pending
-            ev.synchronize()
-            if bool(flag):
-                raise ValueError("cotracker_amd: online chunks must overlap -- the first window_len - step frames of a chunk "
-                                 "have to be the last frames of the previous chunk (predictor.py:225,288-290); the cached "
-                                 "features of the previous call were used for them.  Set model.online_feature_cache = False "
-                                 "to re-encode every chunk in full as the reference does.")
         pending, self._pending_range = getattr(self, "_pending_range", None), None
         if pending is not None:
             flag, ev = pending
@@ -345,13 +344,13 @@ class CoTrackerThreeBase(nn.Module):
         first use of this (shapes, iters, weights) combination, then only refreshed in place and replayed.
         Returns the static coords/vis/conf tensors (overwritten by the next call)."""
         key = (tuple(tuple(f.shape) for f in fm), coords.shape[1], int(iters), id(pw), coords.device.index,
-               int(self.max_corr_rows), tuple(self.model_resolution), int(self.stride))
+               int(self.max_corr_rows), tuple(self.model_resolution), int(self.stride), bool(getattr(self, "_space_attn", True)))
         g = self._graphs.get(key)
         if g is None:
             st_fm = [f.clone() for f in fm]
             st_sup = [s_.clone() for s_ in support]
             win = ops.Window(st_fm, st_sup, coords.clone(), vis.clone(), conf.clone(), self._scale_xy(), iters=iters,
-                             point_mask=mask.clone(), max_corr_rows=self.max_corr_rows)
+                             point_mask=mask.clone(), max_corr_rows=self.max_corr_rows, space_attn=getattr(self, "_space_attn", True))
             self._drop_graphs()  # one live graph per model: a new shape replaces the old one (frees its workspace)
             g = ops.WindowGraph(win, pw)
             self._graphs = {key: g}
@@ -398,9 +397,7 @@ class CoTrackerThreeBase(nn.Module):
     def _check_inputs(self, video, queries, is_train, add_space_attn=True):
         if is_train:
             raise NotImplementedError("inference-only implementation (training is out of scope)")
-        if not add_space_attn:
-            raise NotImplementedError("add_space_attn=False is not built: the HIP update former always runs the "
-                                      "virtual-track space attention (cotracker.py:499-519)")
+        self._space_attn = bool(add_space_attn)  # forward-time flag of the reference (cotracker.py:496-502): time blocks only
         if not video.is_cuda:
             raise RuntimeError("cotracker_amd runs on an MI355X GPU only: move the model and inputs to 'cuda'. "
                                "There is no CPU path.")
@@ -414,6 +411,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
     """Sliding-window / streaming tracker (cotracker3_online.py:159-541)."""
 
     def init_video_online_processing(self):  # cotracker3_online.py:163-169
+        self._resolve_deferred_range_check()  # the last chunk of the previous stream (graph streaming defers its check by one call)
         self.online_ind = 0
         self.online_track_feat = [None] * self.corr_levels  # unused by v3 (SURVEY §4.2), kept for API parity
         self.online_track_support = [None] * self.corr_levels
@@ -472,19 +470,15 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
     def _encode_online(self, video, chunk, S, step):
         """Streaming: consecutive chunks overlap by S - step frames (predictor.py:225,288-290 feeds the last 2*step frames
         every step), and the encoder is per-frame, so the overlapping frames' level-0 features are the ones computed one
-        call ago.  With ``online_feature_cache`` only the `step` NEW frames go through the CNN (half the encoder time of a
-        streaming call).  That the overlapping frames really are the previous chunk's is verified on the device and
-        checked one call later (no host synchronisation in the stream); a mismatch raises."""
+        call ago.  With ``online_feature_cache`` (opt-in) only the `step` NEW frames go through the CNN (half the encoder
+        time of a streaming call).  That the overlapping frames really are the previous chunk's is verified on the device
+        BEFORE the cached features are used (one small device-to-host flag per call); a chunk that does not overlap is
+        simply encoded in full, exactly what the reference does with it."""
         T = video.shape[0]
         ov = S - step
         tail, prev = self.online_f0_tail, self._online_prev_frames
-        if self.online_feature_cache and T == S and tail is not None and tail.shape[0] == ov and prev.shape == video[:ov].shape:
-            bad = (video[:ov] != prev).any()
-            flag = torch.empty((), dtype=torch.bool, pin_memory=True)
-            flag.copy_(bad, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._pending_overlap = (flag, ev)
+        if self.online_feature_cache and T == S and tail is not None and tail.shape[0] == ov and prev.shape == video[:ov].shape \
+                and bool(torch.equal(video[:ov], prev)):
             f0 = torch.cat([tail, self._encode(video[ov:].float(), chunk)], dim=0)
         else:
             f0 = self._encode(video.float(), chunk)
@@ -566,7 +560,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
                 vis = vis_init.clone()
                 conf = conf_init.clone()
                 win = ops.Window(fm, support, coords, vis, conf, self._scale_xy(), iters=iters, point_mask=mask,
-                                 max_corr_rows=self.max_corr_rows)
+                                 max_corr_rows=self.max_corr_rows, space_attn=getattr(self, "_space_attn", True))
                 ops.forward_window(win, pw)
             S_trim = T if is_online else min(T - ind, S)
             coords_pred[ind:ind + S] = (coords * float(self.stride))[:S_trim]
@@ -607,6 +601,6 @@ class CoTrackerThreeOffline(CoTrackerThreeBase):
         vis = torch.zeros(T, N, device=dev)
         conf = torch.zeros(T, N, device=dev)
         win = ops.Window(pyr, support, coords, vis, conf, self._scale_xy(), iters=iters, point_mask=None,
-                         max_corr_rows=self.max_corr_rows)
+                         max_corr_rows=self.max_corr_rows, space_attn=getattr(self, "_space_attn", True))
         ops.forward_window(win, pw)
         return coords * float(self.stride), vis, conf

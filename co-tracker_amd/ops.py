@@ -352,7 +352,8 @@ class Window:
 
     def __init__(self, fmaps: Sequence[torch.Tensor], support: Sequence[torch.Tensor], coords: torch.Tensor,
                  vis: torch.Tensor, conf: torch.Tensor, scale_xy, iters: int = 6,
-                 point_mask: Optional[torch.Tensor] = None, max_corr_rows: int = 262144, use_aux_stream: bool = True):
+                 point_mask: Optional[torch.Tensor] = None, max_corr_rows: int = 262144, use_aux_stream: bool = True,
+                 space_attn: bool = True):
         _chk_f32(*fmaps, *support, coords, vis, conf)
         S, N = coords.shape[0], coords.shape[1]
         assert coords.shape == (S, N, 2) and vis.shape == (S, N) and conf.shape == (S, N)
@@ -371,6 +372,7 @@ class Window:
         a.scale_x, a.scale_y = float(scale_xy[0]), float(scale_xy[1])
         a.points_per_chunk = max(1, min(N, max_corr_rows // S))
         a.aux_stream = aux_stream(coords.device).cuda_stream if use_aux_stream else None
+        a.flags = 0 if space_attn else L.WINDOW_NO_SPACE_ATTN  # add_space_attn=False (cotracker.py:496-502)
         self.args = a
         self.S, self.N = S, N
         self.keep = (list(fmaps), list(support), coords, vis, conf, point_mask)

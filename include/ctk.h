@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 5
+#define CTK_ABI_VERSION 6
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -128,7 +128,10 @@ typedef struct ctk_window_args {
                                  projection beside the virtual-track chain.  Same results, bit for bit (the launches and
                                  their inputs are unchanged; only their stream differs).  Must not be the capture-origin
                                  of another graph; safe inside ctk_window_graph_create (it joins that capture).  */
+  int32_t flags;              /* CTK_WINDOW_NO_SPACE_ATTN: EfficientUpdateFormer.forward(add_space_attn=False) -- only the time
+                                 blocks run, the virtual tracks are still appended and stripped (cotracker.py:496-502,521-523) */
 } ctk_window_args;
+#define CTK_WINDOW_NO_SPACE_ATTN 1
 
 int ctk_abi_version(void);
 const char* ctk_error_string(int code);

@@ -341,7 +341,7 @@ def cross_attn_block(x, context, p, prefix, mask=None):
 # --------------------------------------------------------------------------
 # a-8  EfficientUpdateFormer.forward     cotracker.py:483-531
 # --------------------------------------------------------------------------
-def update_former(x, p, prefix="updateformer.", num_virtual=64, depth=3, mask=None):
+def update_former(x, p, prefix="updateformer.", num_virtual=64, depth=3, mask=None, add_space_attn=True):
     """x [B,N,T,input_dim] -> delta [B,N,T,out].  CoTracker3: depth 3, flow_head(2) ++ vis_conf_head(2), no mask.
     CoTracker2 (cotracker.py:46-56): depth 6, one flow_head of 130 outputs, mask [B*T, N] (attention_mask)."""
     x = np.asarray(x, dtype=f32)
@@ -353,6 +353,8 @@ def update_former(x, p, prefix="updateformer.", num_virtual=64, depth=3, mask=No
     for i in range(depth):
         tt = attn_block(tokens.reshape(B * N, T, C), p, f"{prefix}time_blocks.{i}.")
         tokens = tt.reshape(B, N, T, C)
+        if not add_space_attn:  # cotracker.py:496-502: only the time blocks
+            continue
         st = np.ascontiguousarray(tokens.transpose(0, 2, 1, 3)).reshape(B * T, N, C)
         pt, vt = st[:, : N - num_virtual], st[:, N - num_virtual:]
         vt = cross_attn_block(vt, pt, p, f"{prefix}space_virtual2point_blocks.{i}.", mask)
@@ -439,7 +441,7 @@ def corr_embed(fmaps_pyramid, coords, support_pyramid, p, r=3):
 # a-10 forward_window                    cotracker3_online.py:171-264
 # --------------------------------------------------------------------------
 def forward_window(fmaps_pyramid, coords, support_pyramid, vis, conf, p, iters=4,
-                   model_resolution=(384, 512), stride=4, trace=None):
+                   model_resolution=(384, 512), stride=4, trace=None, add_space_attn=True):
     """Returns final (coords [B,S,N,2] level-0 units, vis logits [B,S,N,1], conf logits)."""
     coords = np.asarray(coords, dtype=f32)
     vis = np.asarray(vis, dtype=f32)
@@ -447,7 +449,7 @@ def forward_window(fmaps_pyramid, coords, support_pyramid, vis, conf, p, iters=4
     for it in range(iters):
         ce = corr_embed(fmaps_pyramid, coords, support_pyramid, p)
         x = assemble_tokens(coords, vis, conf, ce, p["time_emb"], model_resolution, stride)
-        delta = update_former(x, p)
+        delta = update_former(x, p, add_space_attn=add_space_attn)
         d = delta.transpose(0, 2, 1, 3)
         coords = (coords + d[..., :2]).astype(f32)
         vis = (vis + d[..., 2:3]).astype(f32)

@@ -453,6 +453,14 @@ def test_forward_window_vs_oracle_random():
     assert maxdiff(coords, c[0]) < 2.5e-4  # feature units (x4 = px)
     assert maxdiff(vis, v[0, ..., 0]) < 1e-4
     assert maxdiff(conf, cf[0, ..., 0]) < 1e-4
+    # add_space_attn=False (cotracker.py:496-502): time blocks only -- ctk_window_args.flags
+    c2, v2, cf2 = O.forward_window(pyr, cinit, sup, np.zeros((1, S, N, 1), np.float32), np.zeros((1, S, N, 1), np.float32),
+                                   p, iters=2, model_resolution=(192, 256), add_space_attn=False)
+    coords, vis, conf = t(cinit[0]), torch.zeros(S, N, device=dev()), torch.zeros(S, N, device=dev())
+    win = ops.Window(fm, sp, coords, vis, conf, (64.0, 48.0), iters=2, space_attn=False)
+    ops.forward_window(win, m.packed(dev()))
+    assert maxdiff(coords, c2[0]) < 2.5e-4 and maxdiff(vis, v2[0, ..., 0]) < 1e-4 and maxdiff(conf, cf2[0, ..., 0]) < 1e-4
+    assert np.abs(c2 - c).max() > 1e-3
 
 
 # ------------------------------------------------------------------------------------------
@@ -572,8 +580,9 @@ def test_model_online_streaming_hip_graph(golden):
 
 def test_model_online_feature_cache(golden):
     """Streaming re-uses the previous chunk's level-0 features for the overlapping frames (only the `step` new frames go
-    through the CNN): same tracks as re-encoding every chunk in full, and as the reference golden; chunks that do NOT
-    overlap are detected (one call later, without a host sync in the stream) and raise."""
+    through the CNN, opt-in): same tracks as re-encoding every chunk in full, and as the reference golden; chunks that do
+    NOT overlap are detected before the cached features are used and simply encoded in full, as the reference does
+    (predictor.py:288-290) -- identical to the cache-off run, no error."""
     from cotracker_amd.model import CoTrackerThreeOnline
     from cotracker_amd.weights import fill_synthetic_
     g = golden("model_online")
@@ -592,12 +601,57 @@ def test_model_online_feature_cache(golden):
     assert maxdiff(outs[True][0], outs[False][0]) < 3e-4   # the encoder sees 4 instead of 8 frames per call: rounding only
     assert maxdiff(outs[True][0], g["on_stream_coords"]) < 1e-3
     assert maxdiff(logit(outs[True][1]), logit(g["on_stream_vis"])) < 1e-4
+    assert CoTrackerThreeOnline(window_len=8).online_feature_cache is False  # reference semantics by default
+    jumps = {}
+    for cache in (True, False):
+        m.online_feature_cache = cache
+        m.init_video_online_processing()
+        m(video[:, 0:8], q, iters=1, is_online=True)
+        cs, vs, fs, _ = m(video[:, 8:16], q, iters=1, is_online=True)   # NOT the overlapping chunk video[:, 4:12]
+        jumps[cache] = cs.clone()
+    assert maxdiff(jumps[True], jumps[False]) < 1e-4   # both encode the 8 frames in full (MIOpen is not run-to-run bit-stable)
+
+
+def test_model_add_space_attn_false_matches_time_blocks_only(golden):
+    """forward(add_space_attn=False) (cotracker.py:496-502): only the time blocks run.  Checked against the numpy oracle's
+    update former with the space blocks skipped, through the offline model (one window)."""
+    from cotracker_amd.model import CoTrackerThreeOffline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_offline")
+    m = CoTrackerThreeOffline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=1)
+    m = m.to(dev())
+    video, q = t(g["off_video"]), t(g["off_queries"])
+    full = m(video, q, iters=2)[0]
+    time_only = m(video, q, iters=2, add_space_attn=False)[0]
+    again = m(video, q, iters=2, add_space_attn=False)[0]
+    assert torch.isfinite(time_only).all() and maxdiff(time_only, again) < 1e-4   # (MIOpen encoder: not bit-stable run to run)
+    assert maxdiff(full, time_only) > 1e-3          # the space blocks do something
+    assert maxdiff(m(video, q, iters=2)[0], full) < 1e-4   # and the flag does not stick
+
+
+def test_model_copy_and_pickle_with_pending_stream_state(golden):
+    """deepcopy / pickle of a model in the middle of a graph stream (a deferred range check is pending: a pinned flag and a
+    cuda Event, neither picklable) -- ADVICE r2."""
+    import copy
+    import pickle
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_online")
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+    fill_synthetic_(m, seed=1)
+    m = m.to(dev())
+    m.hip_graph = True
     m.online_feature_cache = True
+    video, q = t(g["on_video"]), t(g["on_queries"])
     m.init_video_online_processing()
     m(video[:, 0:8], q, iters=1, is_online=True)
-    m(video[:, 8:16], q, iters=1, is_online=True)          # NOT the overlapping chunk video[:, 4:12]
-    with pytest.raises(ValueError, match="must overlap"):
-        m(video[:, 8:16], q, iters=1, is_online=True)
+    assert (m._pending_range is not None) == (m.precision == "f16x3")  # the exact-f32 back end has no range to guard
+    m2 = copy.deepcopy(m)
+    assert m2._pending_range is None and m2.online_f0_tail is None and m2._graphs == {}
+    m(video[:, 4:12], q, iters=1, is_online=True)
+    m3 = pickle.loads(pickle.dumps(m))
+    assert m3._pending_range is None and m3._packed == {}
 
 
 def test_model_online_batched_streaming(golden):

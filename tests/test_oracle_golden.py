@@ -261,3 +261,30 @@ def test_torch_port_matches_reference_goldens(golden):
     c, v, f = TP.model_forward(fnet, p, torch.from_numpy(g["off_video"]), torch.from_numpy(g["off_queries"]), iters=4, offline=True)
     assert float((c - torch.from_numpy(g["off_coords"])).abs().max()) < 2e-4
     assert float((v.double() - lg(g["off_vis"])).abs().max()) < 1e-4
+
+
+def test_update_former_add_space_attn_false_matches_reference():
+    """EfficientUpdateFormer.forward(add_space_attn=False) (cotracker.py:496-502): the oracle against the imported reference
+    (build container only: /root/reference does not travel)."""
+    import os
+    import sys
+    if not os.path.isdir("/root/reference/cotracker"):
+        pytest.skip("reference checkout not present")
+    import torch
+    sys.path.insert(0, "/root/reference")
+    from cotracker.models.core.cotracker.cotracker import EfficientUpdateFormer
+    from oracle import cotracker_oracle as O
+    torch.manual_seed(0)
+    f = EfficientUpdateFormer(space_depth=3, time_depth=3, input_dim=1110, hidden_size=384, output_dim=4, mlp_ratio=4.0,
+                              num_virtual_tracks=64, add_space_attn=True, linear_layer_for_vis_conf=True).eval()
+    for _, p_ in f.named_parameters():
+        if p_.dim() > 1:
+            torch.nn.init.normal_(p_, std=0.05)
+    x = torch.randn(1, 5, 8, 1110)
+    with torch.no_grad():
+        y = f(x, add_space_attn=False).numpy()
+        y_full = f(x).numpy()
+    p = {"updateformer." + k: v.numpy() for k, v in f.state_dict().items()}
+    assert np.abs(O.update_former(x.numpy(), p, add_space_attn=False) - y).max() < 5e-5
+    assert np.abs(O.update_former(x.numpy(), p) - y_full).max() < 5e-5
+    assert np.abs(y - y_full).max() > 1e-2

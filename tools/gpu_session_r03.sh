@@ -34,8 +34,8 @@ if has bench; then
 fi
 if has more; then
   for w in c2_offline c4_online c5_shard c3_offline c3_offline_g40 c1_standin v2_sliding; do
-    st=3; [[ $w == c4_online ]] && st=12; [[ $w == c5_shard || $w == c3_offline* || $w == v2_sliding ]] && st=2
-    (timeout 600 python bench.py --workload $w --steps $st --warmup 1 --no-cpu-baseline 2>gpurun_out/r03_bench_$w.err | tail -1) > gpurun_out/r03_bench_$w.json
+    st=3; wu=1; [[ $w == c4_online ]] && { st=12; wu=3; }; [[ $w == c5_shard || $w == c3_offline* || $w == v2_sliding ]] && st=2
+    (timeout 600 python bench.py --workload $w --steps $st --warmup $wu --no-cpu-baseline 2>gpurun_out/r03_bench_$w.err | tail -1) > gpurun_out/r03_bench_$w.json
     summ $w gpurun_out/r03_bench_$w.json
   done
   (timeout 600 python bench.py --precision f32 --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/r03_bench_c3_f32.err | tail -1) > gpurun_out/r03_bench_c3_f32.json
