@@ -152,6 +152,14 @@ SYMBOLS = {
     "ctk_corrblock_sample": (C.c_int, [_P(_fp), _P(C.c_int32), _P(C.c_int32), C.c_int32, C.c_int32, _fp, _fp, _fp, _fp]),
     "ctk_normalize_to_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_avg_pool2_nhwc": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
+    "ctk_conv2d_sh": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int32, _fp, _fp, _fp]),
+    "ctk_enc_stem_im2col": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
+    "ctk_enc_inorm_workspace_bytes": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _P(C.c_size_t)]),
+    "ctk_enc_inorm_stats": (C.c_int, [_fp, C.c_int32, C.c_int64, C.c_int32, C.c_float, _fp, _fp, _fp]),
+    "ctk_enc_inorm_apply": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp]),
+    "ctk_enc_fuse": (C.c_int, [_P(_fp), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _fp, _fp]),
+    "ctk_enc_l2norm": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "ctk_gemm": (C.c_int, [_P(GemmArgs), _fp]),
     "ctk_pack_weight_bytes": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_size_t)]),
     "ctk_pack_weight": (C.c_int, [_fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp]),

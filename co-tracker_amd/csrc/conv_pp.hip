@@ -1,0 +1,258 @@
+// The encoder's convolutions (BasicEncoder, cotracker/models/core/cotracker/blocks.py:141-219; called at
+// cotracker3_online.py:373-384) as IMPLICIT GEMMs on the split-half MFMA path -- no im2col matrix, no MIOpen.
+//
+//   out[(f, oy, ox)][n] = bias[n] + sum_{ky,kx,c} in[f][oy*s + ky - pad][ox*s + kx - pad][c] * W[n][ky][kx][c]
+//
+// Activations live NHWC in SH format, [F][H][W][C/32] lines of 128 bytes (32 hi | 32 lo halves): one K-tile of the GEMM
+// = one (tap, 32-channel group) = ONE such line per output pixel, which is exactly the LDS-DMA granule of gemm_pp.hip.
+// So the A operand of a 256-row tile is fetched by 32 global_load_lds pieces per K-tile whose per-lane source address is
+// the tap-shifted pixel's line (or a 128-byte line of zeros for the padding ring); weights are repacked once to
+// [N][ky][kx][c] and split by ctk_pack_weight; everything behind the LDS ring -- fragments, the 3 x f16 MFMA products,
+// the ping-pong of the two wave groups, the LDS-transposed full-line stores -- is gemm_pp.hip's.
+//
+// One tile shape for all 22 convolutions: 256 output pixels x 128 output channels (waves 4 x 2, wave tile 64 x 64: two
+// column phases of 12 MFMAs per K-tile).  Output widths 64 and 96 run on zero-padded weight rows (their columns are not
+// stored); 256 outputs (conv2) are two column blocks.  Ring = 3 K-tiles of 48 KiB: both blocks of K-tile J+2 are
+// requested while K-tile J is multiplied (2-3 phases ahead of their first read), K-tile J-1's slot is the one they land
+// in (its last read is 2 phases old).  The DMA stream does NOT run across tiles here (a convolution tile has 18-117
+// K-tiles; the per-lane pixel decode stays per tile), so the ring is idle at a tile's end and serves as the epilogue's
+// transpose scratch.
+#include "pp_common.h"
+
+namespace {
+
+struct CtkConvP {
+  CtkGemmP g;              // A = SH input, M = F*Hout*Wout, N = padded width (multiple of 128), K = KH*KW*Cin, C/ldc, bias, Wp
+  int F, Hin, Win, CL;     // input frames / size / 32-channel groups per pixel
+  int Hout, Wout, KH, KW, stride, pad;
+  int n_valid;             // stored output columns
+  const unsigned char* zeros;  // >= 128 bytes of zeros (padding ring)
+};
+
+constexpr int CV_SLOT = 49152;          // one K-tile: A 256 rows (32 KiB) | B_0 64 rows | B_1 64 rows
+constexpr int CV_RING = 3 * CV_SLOT;    // 144 KiB
+constexpr int CV_BIAS = 147456;         // bias (<= 4 KiB) behind the ring
+
+template <int EPI>
+__global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_total) {
+  constexpr bool DBG = false;
+  constexpr int BM = 256, BN = 128;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS_ALL];
+  static_assert(CV_BIAS + 4096 <= PP_LDS_ALL, "LDS budget");
+  const CtkGemmP& g = p.g;
+  const int dbg = 0;
+  const int KT = g.K / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  unsigned jctr = 0;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+  const unsigned l3 = lane >> 3, l4 = lane >> 4, l7 = lane & 7;
+
+  const float w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
+  const float* bias_lds = reinterpret_cast<const float*>(lds + CV_BIAS);
+  if ((EPI & 32) != 0) {
+    for (int i = tid; i < g.N / 4; i += 512) reinterpret_cast<f32x4*>(lds + CV_BIAS)[i] = reinterpret_cast<const f32x4*>(g.bias)[i];
+    __syncthreads();
+  }
+
+  const unsigned char* in = static_cast<const unsigned char*>(g.A);
+  const unsigned char* wsh = reinterpret_cast<const unsigned char*>(g.Wp) + PP_HDR_BYTES;
+  const unsigned ldw_b = (unsigned)KT * 128;
+  const int hw_out = p.Hout * p.Wout;
+  const int taps_w = p.KW, cl = p.CL;
+
+  // block-piece q (0..23) of the second block of a K-tile: A pieces 24..31 | B_0 pieces 0..7 | B_1 pieces 0..7
+  auto cbyte = [&](const int piece) { return ((l7 ^ ((4 * piece + l4) & 7)) << 4); };
+
+  // fragment addressing (as gemm_pp192_kernel): [j][plane], slot offset added per K-tile
+  const int fsw = (r32 >> 1) & 7;
+  unsigned a_rd0[2][2], b_rd0[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const unsigned co = (unsigned)(((pl * 4 + j * 2 + half) ^ fsw) << 4);
+      a_rd0[j][pl] = (wm * 64 + r32) * 128 + co;
+      b_rd0[j][pl] = 32768 + (wn * 32 + r32) * 128 + co;
+    }
+
+  f32x16 acc[2][2];
+  f16x8 fa[2][2][2], fb[2][2];
+
+  for (int q = 0;; ++q) {  // my tiles
+    const int G = gridDim.x, first = q * G;
+    if (first >= tiles_total) break;
+    const int n_r = min(G, tiles_total - first);
+    if ((int)blockIdx.x >= n_r) break;
+    unsigned tile = first + ctk_xcd_remap(blockIdx.x, n_r);
+    const int nb = tile % g.nblocks;
+    const int mb = tile / g.nblocks;
+    const int m0 = mb * BM, n0 = nb * BN;
+
+    // ---- per-lane decode of my A rows: first block pieces 3w+e (e < 3), second block pieces 24 + 3w + e while 3w + e < 8
+    int pix[6], iyx[6];  // pixel index of (f, 0, 0) in the input; packed (iy0 + 0x4000) << 16 | (ix0 + 0x4000)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int piece = k < 3 ? 3 * wave + k : 24 + 3 * wave + (k - 3);
+      const int r = min(m0 + 8 * piece + (int)l3, g.M - 1);
+      const int f = r / hw_out, rem = r - f * hw_out;
+      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      pix[k] = f * p.Hin * p.Win;
+      iyx[k] = ((oy * p.stride - p.pad + 0x4000) << 16) | (ox * p.stride - p.pad + 0x4000);
+    }
+    auto a_src = [&](const int k, const int piece, const int ky, const int kx, const int ct) -> const unsigned char* {
+      const int iy = (iyx[k] >> 16) - 0x4000 + ky, ix = (iyx[k] & 0xffff) - 0x4000 + kx;
+      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      const long off = ((long)(pix[k] + iy * p.Win + ix) * cl + ct) * 128;
+      return (ok ? in + off : p.zeros) + cbyte(piece);
+    };
+    // K-tile kt = (tap, channel group): tap-major, channel group fastest (the weight repack order)
+    auto issue_i0 = [&](int kt, const int slot) {  // A pieces 3w .. 3w+2
+      kt = min(kt, KT - 1);
+      const int tap = kt / cl, ct = kt - tap * cl, ky = tap / taps_w, kx = tap - ky * taps_w;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int piece = 3 * wave + e;
+        __builtin_amdgcn_global_load_lds((pp_gptr)a_src(e, piece, ky, kx, ct), (pp_lptr)(lds + slot * CV_SLOT + piece * 1024), 16, 0, 0);
+      }
+    };
+    auto issue_i1 = [&](int kt, const int slot) {  // block pieces 3w .. 3w+2 of [A 24..31 | B_0 | B_1]
+      kt = min(kt, KT - 1);
+      const int tap = kt / cl, ct = kt - tap * cl, ky = tap / taps_w, kx = tap - ky * taps_w;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int bq = 3 * wave + e;
+        if (bq < 8) {
+          const int piece = 24 + bq;
+          __builtin_amdgcn_global_load_lds((pp_gptr)a_src(3 + e, piece, ky, kx, ct), (pp_lptr)(lds + slot * CV_SLOT + piece * 1024), 16, 0, 0);
+        } else {
+          const int n = (bq - 8) >> 3, piece = (bq - 8) & 7;  // B_n piece: W rows n0 + n*64 + 8*piece + l3
+          const unsigned char* src = wsh + (long)(n0 + n * 64 + 8 * piece + (int)l3) * ldw_b + (long)kt * 128 + cbyte(piece);
+          __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + slot * CV_SLOT + 32768 + n * 8192 + piece * 1024), 16, 0, 0);
+        }
+      }
+    };
+
+    // ---- prologue of the tile: K-tiles 0 and 1 requested, K-tile 0 waited for
+    issue_i0(0, 0);
+    issue_i1(0, 0);
+    issue_i0(1, 1);
+    issue_i1(1, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    PP_WAIT_VM(6);  // the 6 pieces of K-tile 1 may still be in flight
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();  // stagger in
+
+    int slot = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      const int slot2 = slot == 0 ? 2 : slot - 1;  // slot of K-tile kt + 2 (= of K-tile kt - 1)
+      const unsigned so = slot * CV_SLOT;
+      // ---- phase 0: read A, B_0; request the A rows 0..191 of K-tile kt+2
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa[mi][j][pl] = *reinterpret_cast<const f16x8*>(lds + so + a_rd0[j][pl] + mi * 4096);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl]);
+      issue_i0(kt + 2, slot2);
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][0], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      PP_BARRIER();
+      // ---- phase 1: read B_1; request the rest of K-tile kt+2; K-tile kt+1 must have landed
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl] + 8192);
+      issue_i1(kt + 2, slot2);
+      PP_WAIT_VM(6);
+      PP_BARRIER();
+      PP_WAIT_LGKM0();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][1], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (kt + 1 < KT) PP_BARRIER();
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    // ---- tile end: drop the stagger, drain the duplicate tail requests, then the ring is the transpose scratch
+    if (grp == 0) PP_BARRIER();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    {
+      const int mrow = m0 + wm * 64, ncol = n0 + wn * 32;
+      pp_epilogue<EPI, 2, 2>(g, acc, lane, 0, w_unscale, bias_lds, lds + wave * 4096, [&](int mi) { return mrow + mi * 32; },
+                             [&](int ni) { return ncol + ni * 64; }, false, p.n_valid);
+    }
+    PP_BARRIER();  // scratch reads done before the next tile's prologue lands in the ring
+  }
+}
+
+}  // namespace
+
+// in_sh: SH activations NHWC [F][Hin][Win][Cin/32] lines; wp: ctk_pack_weight of the [Npad][KH*KW*Cin] matrix ([n][ky][kx][c] order,
+// rows >= n_out zero); bias: Npad floats; out: f32 [F*Hout*Wout][n_out]; zeros: >= 128 zero bytes on the device.
+extern "C" int ctk_conv2d_sh(const void* in_sh, int32_t F, int32_t Hin, int32_t Win, int32_t Cin, const void* wp, const float* bias,
+                             int32_t n_out, int32_t n_pad, int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* out,
+                             const void* zeros, void* stream) {
+  if (!in_sh || !wp || !bias || !out || !zeros) return CTK_E_NULL;
+  if (F <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || (Cin % 32) || n_out <= 0 || n_pad < n_out || (n_pad % 128) || (n_out % 32) ||
+      n_pad > 1024 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || Hin > 16000 || Win > 16000)
+    return CTK_E_SHAPE;
+  if (!ctk_aligned16(in_sh) || !ctk_aligned16(wp) || !ctk_aligned16(bias) || !ctk_aligned16(out) || !ctk_aligned16(zeros)) return CTK_E_ALIGN;
+  const int Hout = (Hin + 2 * pad - KH) / stride + 1, Wout = (Win + 2 * pad - KW) / stride + 1;
+  if (Hout <= 0 || Wout <= 0) return CTK_E_SHAPE;
+  const long M = (long)F * Hout * Wout;
+  if (M > 0x7fffffffL || (long)F * Hin * Win > 0x7fffffffL) return CTK_E_SHAPE;
+  CtkConvP p;
+  CtkGemmP& g = p.g;
+  g = CtkGemmP{};
+  g.A = in_sh; g.lda = 0; g.M = (int)M;
+  g.N = n_pad; g.K = KH * KW * Cin;
+  g.Wp = static_cast<const unsigned short*>(wp);
+  g.C = out; g.ldc = n_out;
+  g.bias = bias;
+  g.act = CTK_ACT_NONE;
+  g.batch = 1;
+  g.mblocks = (int)((M + 255) / 256); g.nblocks = n_pad / 128;
+  p.F = F; p.Hin = Hin; p.Win = Win; p.CL = Cin / 32;
+  p.Hout = Hout; p.Wout = Wout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.n_valid = n_out;
+  p.zeros = static_cast<const unsigned char*>(zeros);
+  const long tiles = (long)g.mblocks * g.nblocks;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (cus <= 0) cus = 256;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char pname[48];
+  snprintf(pname, sizeof(pname), "conv_pp128_%dx%d_s%d_c%d_n%d", KH, KW, stride, Cin, n_out);
+  const double flops = 2.0 * M * (double)n_out * g.K;
+  CtkProfScope ps(pname, flops, 4.0 * ((double)F * Hin * Win * Cin + (double)M * n_out), s);
+  hipLaunchKernelGGL((conv_pp128_kernel<32>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p, (int)tiles);
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}

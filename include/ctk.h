@@ -279,6 +279,40 @@ int ctk_corrblock_sample(const float* const* fmaps, const int32_t* H, const int3
 int ctk_normalize_to_nhwc(const float* in, int32_t F, int32_t H, int32_t W, float* out, void* stream);
 int ctk_avg_pool2_nhwc(const float* in, int32_t F, int32_t H, int32_t W, float* out, void* stream);
 
+/* ---- CNN feature encoder on the split-half MFMA path (round 3) ---------------------------------------------
+ * BasicEncoder (cotracker/models/core/cotracker/blocks.py:141-219, ResidualBlock :79-138), called once per forward at
+ * cotracker3_online.py:373-384 / cotracker3_offline.py:60-75.  Activations are NHWC; a convolution reads SH-format input
+ * ([pixel][C/32] lines of 128 bytes: 32 hi | 32 lo halves, see the SH notes below) and writes f32 [pixel][n_out].  The host
+ * side (co-tracker_amd/encoder_hip.py) strings these calls together in the reference's order.
+ *
+ * ctk_conv2d_sh: nn.Conv2d(Cin, n_out, (KH,KW), stride, padding=pad, zeros) as an implicit GEMM (no im2col buffer).
+ *   in_sh  [F][Hin][Win][Cin/32] lines; Cin % 32 == 0
+ *   wp     ctk_pack_weight blob of the matrix W'[n_pad][KH*KW*Cin], W'[n][(ky*KW+kx)*Cin + c] = weight[n][c][ky][kx], rows
+ *          n >= n_out zero, n_pad % 128 == 0; bias: n_pad floats (zeros beyond n_out)
+ *   out    f32 [F*Hout*Wout][n_out], Hout = (Hin + 2 pad - KH)/stride + 1; zeros: >= 128 zero bytes on the device          */
+int ctk_conv2d_sh(const void* in_sh, int32_t F, int32_t Hin, int32_t Win, int32_t Cin, const void* wp, const float* bias,
+                  int32_t n_out, int32_t n_pad, int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* out,
+                  const void* zeros, void* stream);
+/* Stem: x = 2*(frame/255) - 1 (cotracker3_online.py:320) and the 7x7 stride-2 pad-3 patches of the 3-channel frames
+ * [F,3,H,W] as SH rows of 160 columns ((ky,kx,c) order, 147 used, rest 0): conv1 (blocks.py:150-157) = ctk_conv2d_sh on
+ * a [F][Ho][Wo] grid with Cin = 160, 1x1, stride 1.  out_sh: F*Ho*Wo*160*4 bytes, Ho = (H-1)/2+1.                         */
+int ctk_enc_stem_im2col(const float* frames, int32_t F, int32_t H, int32_t W, void* out_sh, void* stream);
+/* nn.InstanceNorm2d (no affine, eps, biased variance; blocks.py:110-113,147-148) statistics of x f32 [F][HW][C]:
+ * stats [F][C][2] = (mean, 1/sqrt(var + eps)), sums in f64 in a fixed order.  workspace: ctk_enc_inorm_workspace_bytes.    */
+int ctk_enc_inorm_workspace_bytes(int32_t F, int64_t HW, int32_t C, size_t* out_bytes);
+int ctk_enc_inorm_stats(const float* x, int32_t F, int64_t HW, int32_t C, float eps, float* stats, void* workspace, void* stream);
+/* y = relu((x - mean) * rstd)  (blocks.py:130-131, 188-190, 216-217); with skip: out = relu(skip' + y) (blocks.py:138) where
+ * skip' = skip, or (skip - mean_s) * rstd_s when skip_stats is given (the 1x1 downsample branch, blocks.py:123-126,133-136).
+ * Writes SH (out_sh, the next convolution's input) and / or f32 (out_f32); C % 32 == 0.                                    */
+int ctk_enc_inorm_apply(const float* x, const float* stats, const float* skip, const float* skip_stats, int32_t F, int64_t HW,
+                        int32_t C, void* out_sh, float* out_f32, void* stream);
+/* F.interpolate(., (Ho, Wo), bilinear, align_corners=True) of the four stage outputs (f32 NHWC [F][H_k][W_k][C_k]) and
+ * torch.cat over channels (blocks.py:198-215) -> SH [F][Ho][Wo][sum C_k / 32] lines, the input of conv2.                    */
+int ctk_enc_fuse(const float* const* src, const int32_t* H, const int32_t* W, const int32_t* C, int32_t F, int32_t Ho, int32_t Wo,
+                 void* out_sh, void* stream);
+/* fmaps / sqrt(max(sum_c fmaps^2, 1e-12)) on NHWC [P][128] (cotracker3_online.py:384-394).                                  */
+int ctk_enc_l2norm(const float* x, int64_t P, float* out, void* stream);
+
 /* ---- primitives (exported for unit tests and reuse) ------------------------------ */
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N] + bias_rows[(m % period),N]) + resid[M,N]
  * N % 64 == 0, K % 32 == 0, lda/ldw % 4 == 0, A and W 16-byte aligned.  batch > 1 repeats with
