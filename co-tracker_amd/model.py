@@ -226,6 +226,7 @@ class CoTrackerThreeBase(nn.Module):
         self.corr_mlp = _Mlp(49 * 49, 384, 256)
         self.register_buffer("time_emb", sincos_time_embed(self.input_dim, window_len))
         self._packed = {}  # precision -> PackedWeights
+        self._hip_encoder = None  # encoder_hip.HipEncoder for the current device (repacked convolution weights)
         self.max_corr_rows = 262144  # (point,frame) rows of correlation volume resident at once (~10 GB)
         # arithmetic of the Linear layers: "f16x3" = split-half MFMA (3 f16 MFMAs per product, f32 accumulate,
         # fp32-class accuracy at 5.3x the f32-MFMA ceiling), "f32" = exact-f32 MFMA.  Not a reference kwarg.
@@ -242,6 +243,10 @@ class CoTrackerThreeBase(nn.Module):
         self.range_guard = True
         self.range_fallbacks = 0
         self.encoder_dtype = torch.float32  # fp32 as the reference; see tools/probe_encoder_precision.py for why not lower
+        # "hip" (default): the CNN runs on the library's split-half implicit-GEMM convolutions (encoder_hip.py, csrc/conv_pp.hip,
+        # csrc/encoder.hip) -- fp32-class accuracy at 2.2x the speed of MIOpen's fp32 convolutions; "torch": nn.Conv2d on
+        # PyTorch-ROCm / MIOpen (the round-1/2 path, kept for A/B and for `encoder_dtype` experiments).  Not a reference kwarg.
+        self.encoder_backend = "hip"
         # streaming: reuse the previous chunk's features for the overlapping frames (see _encode_online).  Not a reference
         # kwarg and OFF by default (the reference re-encodes whatever chunk it is given, predictor.py:288-290); opt in for
         # streams whose chunks overlap by window_len - step frames (bench.py's configs[3] workload does)
@@ -269,6 +274,7 @@ class CoTrackerThreeBase(nn.Module):
     def invalidate_packed_weights(self):
         """Call after mutating parameters in place (e.g. weights.fill_synthetic_)."""
         self._packed = {}
+        self._hip_encoder = None
         self._drop_graphs()  # captured graphs hold pointers into the old packed weights
 
     def _drop_graphs(self):
@@ -280,7 +286,7 @@ class CoTrackerThreeBase(nn.Module):
             self._graphs = {}
 
     # device-side caches (ctypes structs with raw pointers) are rebuilt on demand: keep them out of pickles / deep copies
-    _TRANSIENT = {"_packed": dict, "_graphs": dict, "_pending_range": type(None), "_pending_overlap": type(None),
+    _TRANSIENT = {"_packed": dict, "_graphs": dict, "_hip_encoder": type(None), "_pending_range": type(None), "_pending_overlap": type(None),
                   "online_f0_tail": type(None), "_online_prev_frames": type(None)}
 
     def __getstate__(self):
@@ -381,6 +387,14 @@ class CoTrackerThreeBase(nn.Module):
         T, _, H, W = frames.shape
         step = max(1, min(int(chunk), int(self.encoder_chunk)))
         out = torch.empty(T, H // self.stride, W // self.stride, self.latent_dim, device=frames.device, dtype=torch.float32)
+        if self.encoder_backend == "hip" and self.encoder_dtype == torch.float32:
+            enc = getattr(self, "_hip_encoder", None)
+            if enc is None or enc.device != frames.device:
+                from .encoder_hip import HipEncoder
+                enc = self._hip_encoder = HipEncoder(self.fnet, frames.device)
+            for t0 in range(0, T, step):
+                enc(frames[t0:t0 + step].float().contiguous(), out=out[t0:t0 + step])
+            return out
         for t0 in range(0, T, step):
             x = 2 * (frames[t0:t0 + step] / 255.0) - 1.0  # cotracker3_online.py:320
             if self.encoder_dtype == torch.float32:
