@@ -491,8 +491,14 @@ def main():
         traffic = {}
         if os.path.exists(args.pmc_traffic):
             traffic = json.load(open(args.pmc_traffic))
-            if traffic.pop("_workload", "c3_sliding") != args.workload:
-                traffic = {}  # the PMC passes were collected on another workload: per-launch bytes do not transfer
+            import hashlib
+            so = os.path.join(ROOT, "co-tracker_amd", "libctk_hip.so")
+            so_hash = hashlib.sha256(open(so, "rb").read()).hexdigest()
+            stamp = traffic.pop("_lib_sha256", None)
+            result["traffic_source"] = {"file": os.path.relpath(args.pmc_traffic, ROOT), "lib_sha256": stamp, "this_lib_sha256": so_hash,
+                                        "fresh": stamp == so_hash}
+            if traffic.pop("_workload", "c3_sliding") != args.workload or stamp != so_hash:
+                traffic = {}  # the PMC passes were collected on another workload or another build of the kernels: bytes do not transfer
         gemm_rows = [r for r in rows if r["name"].startswith(("gemm_sh", "gemm_f16x3", "gemm_f32", "mlp_sh"))]
         if rows:
             dom = rows[0]

@@ -93,7 +93,7 @@ __device__ __forceinline__ void pp_cursor_next(const CtkGemmP& g, int tiles_tota
 // every wave has waited for its pieces of blocks <= g + 2 at the end of the load segment of phase g (vmcnt(8): the 4
 // younger blocks stay in flight), one s_barrier before any wave reads them.
 // LDS: A blocks at (J&1)*32K + a*16K, B blocks at 64K + (J&1)*32K + b*16K.
-template <int EPI, bool DBG>
+template <int EPI, bool DBG, int TAG = 0>  // TAG: no code difference, only a distinct kernel NAME per Linear for rocprofv3 (tools/pmc_traffic.py)
 __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
   const int dbg = DBG ? dbg_arg : 0;  // the experiment knobs exist only in the DBG instantiations
   constexpr int BM = 256, BN = 256;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
 // block i = 3 J + k is issued in phase i - 4 into the K-tile slot (J & 1) (56 KiB each), where block i - 6 was last read
 // >= 2 phases earlier; waits: end of phase 3J+2 -> I0, I1 of K-tile J+1 (vmcnt(5): I2(J+1) and I0(J+2) stay in flight),
 // end of phase 3J -> I2 of K-tile J (vmcnt(5)), end of phase 3J+1 -> nothing new.
-template <int EPI, bool DBG>
+template <int EPI, bool DBG, int TAG = 0>
 __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
   const int dbg = DBG ? dbg_arg : 0;
   constexpr int BM = 256, BN = 192;
@@ -508,7 +508,8 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
     if (t256 && dbgk) hipLaunchKernelGGL((gemm_pp256_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);   \
     else if (t256) hipLaunchKernelGGL((gemm_pp256_kernel<E, false>), grid, blk, 0, s, g, (int)tiles, 0);       \
     else if (dbgk) hipLaunchKernelGGL((gemm_pp192_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);      \
-    else hipLaunchKernelGGL((gemm_pp192_kernel<E, false>), grid, blk, 0, s, g, (int)tiles, 0);                 \
+    else if (g.K > 768) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
+    else hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 0>), grid, blk, 0, s, g, (int)tiles, 0);              \
     break
   switch (code) {
     PP_CASE(pp_epi(CTK_ACT_GELU_ERF, false, true, false, true));    // corr_mlp.fc1

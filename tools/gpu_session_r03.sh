@@ -44,18 +44,26 @@ if has more; then
   summ 2rank gpurun_out/r03_bench_2rank_gloo_single_device_tiny.json
 fi
 if has prof; then
-  cd /tmp && rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats -d /tmp/prof -o r03 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /tmp/prof_bench.log 2>&1
+  cd /tmp && rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /tmp/prof_bench.log 2>&1
   cd $GRAFT_REPO_ROOT
-  f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
-  python tools/summarize_rocprof.py "$f" > gpurun_out/r03_rocprof_kernel_stats.txt 2>&1 || cp "$f" gpurun_out/r03_rocprof_kernel_stats.csv
-  head -30 gpurun_out/r03_rocprof_kernel_stats.txt
+  python tools/summarize_rocprof.py /tmp/prof gpurun_out/r03_rocprof_kernel_stats.txt 2>&1 | tail -3
+  tail -5 /tmp/prof_bench.log | cut -c1-300
+  head -34 gpurun_out/r03_rocprof_kernel_stats.txt
+fi
+if has sq; then
+  cd /tmp && rm -rf /tmp/sq /tmp/ldsc
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d /tmp/sq -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /tmp/sq.log 2>&1
+  rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/ldsc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /tmp/ldsc.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/summarize_counters.py /tmp/sq gpurun_out/r03_sq_counters.txt | head -24
+  python tools/summarize_counters.py /tmp/ldsc gpurun_out/r03_lds_counters.txt | head -14
 fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    cd /tmp && rm -rf /tmp/pmc_$c && rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o r03 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /tmp/pmc_$c.log 2>&1
+    cd /tmp && rm -rf /tmp/pmc_$c && rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /tmp/pmc_$c.log 2>&1
     cd $GRAFT_REPO_ROOT
   done
-  python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > gpurun_out/r03_pmc_traffic.txt 2>&1
-  cp profiles/pmc_traffic.json gpurun_out/r03_pmc_traffic.json 2>/dev/null
-  tail -30 gpurun_out/r03_pmc_traffic.txt
+  ff=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py "$ff" "$fw" gpurun_out/r03_pmc_traffic.json c3_sliding > gpurun_out/r03_pmc_traffic.txt 2>&1
+  head -30 gpurun_out/r03_pmc_traffic.txt
 fi

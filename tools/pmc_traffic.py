@@ -16,6 +16,23 @@ import re
 import sys
 
 NAME_MAP = [
+    # round 3: the persistent ping-pong kernels (gemm_pp.hip).  Template arguments <EPI, DBG, TAG>: the epilogue code names the
+    # Linear (42 mlp.fc1, 32 to_q / to_kv, 40 corr_mlp.fc2, 41 corr_mlp.fc1, 16 input_transform, 36 to_out / mlp.fc2), TAG = 1
+    # marks K > 768 (mlp.fc2 against to_out, corr_mlp.fc1, input_transform).  to_q and to_out share one recorder row in bench.py.
+    (r"gemm_pp256_kernel<42,", "gemm_sh_pp256_k384_n1536"),
+    (r"gemm_pp256_kernel<32,", "gemm_sh_pp256_k384_n768"),
+    (r"gemm_pp256_kernel<40,", "gemm_sh_pp256_k384_n256"),
+    (r"gemm_pp192_kernel<41,", "gemm_sh_pp192_k2432_n384"),
+    (r"gemm_pp192_kernel<16,", "gemm_sh_pp192_k1120_n384"),
+    (r"gemm_pp192_kernel<36, false, 1>", "gemm_sh_pp192_k1536_n384"),
+    (r"gemm_pp192_kernel<36,", "gemm_sh_pp192_k384_n384"),
+    (r"gemm_pp192_kernel<32,", "gemm_sh_pp192_k384_n384"),
+    (r"gemm_sh_deep64_kernel", "gemm_sh_64x64"),
+    (r"conv_pp128_kernel", "conv_pp128"),
+    (r"enc_inorm_partial_kernel", "enc_inorm_stats"),
+    (r"enc_inorm_apply_kernel", "enc_inorm_apply"),
+    (r"enc_stem_im2col_kernel", "enc_stem_im2col"),
+    (r"enc_fuse_kernel", "enc_fuse"),
     # the compile-time epilogue code (last template argument) identifies the Linear where it is unique, which lets the
     # per-shape recorder rows of bench.py (gemm_sh_<tile>_k<K>_n<N>) pick up their own traffic:
     #   256x256: 42 = mlp.fc1 (tanh-GELU, SH out), 32 = to_kv (bias only), 40 = corr_mlp.fc2 (SH out)
@@ -89,6 +106,11 @@ def main():
     lib_names = {nm for _, nm in NAME_MAP}
     keep = {k: v for k, v in res.items() if k in lib_names}
     keep["_workload"] = workload  # bench.py attaches `traffic` only to this workload's roofline
+    # which build of the library the counters were collected on: bench.py refuses to attach traffic measured on another build
+    import hashlib
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "co-tracker_amd", "libctk_hip.so")
+    keep["_lib_sha256"] = hashlib.sha256(open(so, "rb").read()).hexdigest() if os.path.exists(so) else None
     json.dump(keep, open(out, "w"), indent=1)  # library kernels only (others are printed)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:28s} n={v['dispatches']:6d}  fetch {v['fetch_bytes_per_launch'] or 0:14.0f} B  write {v['write_bytes_per_launch'] or 0:14.0f} B")
