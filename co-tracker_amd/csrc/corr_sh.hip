@@ -293,13 +293,16 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
     __syncthreads();
 
     // (5) staging row -> SH volume row: 4 consecutive outputs per thread, hi / lo halves
+    // Round 3: FULL 128-byte lines per 8 lanes.  A CU retires a store instruction only every ~100 cycles whatever its width
+    // (tools/gemm_lab.cpp store experiments), and the 8-byte hi / lo pieces of round 2 were 24 wave-instructions per frame;
+    // lane (line, chunk c) now writes 16 bytes -- hi halves of 8 outputs for c < 4, their lo halves for c >= 4 (both lanes of
+    // an octet split the same 8 values) -- 76 lines x 8 lanes = 10 wave-instructions per frame, each a run of whole lines.
     _Float16* orow = out_base + (long)tl * ROW_H;
-    for (int qd = tid; qd < QUADS; qd += 256) {
-      f16x4 hi, lo;
-      ctk_split4(reinterpret_cast<const f32x4*>(stg)[qd], hi, lo);
-      _Float16* dst = orow + ctk_sh_col(qd * 4);
-      *reinterpret_cast<f16x4*>(dst) = hi;
-      *reinterpret_cast<f16x4*>(dst + 32) = lo;
+    for (int idx = tid; idx < (CTK_CORR_LD / 32) * 8; idx += 256) {
+      const int line = idx >> 3, c = idx & 7, oct = line * 4 + (c & 3);
+      f16x8 hi, lo;
+      ctk_split8(reinterpret_cast<const f32x4*>(stg)[2 * oct], reinterpret_cast<const f32x4*>(stg)[2 * oct + 1], hi, lo);
+      *reinterpret_cast<f16x8*>(orow + line * 64 + c * 8) = (c < 4) ? hi : lo;
     }
     __syncthreads();
   }

@@ -81,3 +81,10 @@ check("pp192", 3,
       ([(0, "I0", 3), (0, "I1", 2), (0, "I2", 2), (1, "I0", 3)], 5),
       [(["I0", "I1"], (1, "I1", 2), 5), (["I2"], (1, "I2", 2), None), (["I2"], (2, "I0", 3), 5)],
       slot_of=lambda k: {"I0": 1, "I1": 2, "I2": 4}[k], ring_kt=2)
+
+# ---- conv_pp128 (conv_pp.hip): 2 phases per K-tile, ring of 3 K-tiles, both blocks of K-tile J+2 requested during K-tile J
+all_kinds = ["I0", "I1"]
+check("conv_pp128", 2,
+      ([(0, "I0", 3), (0, "I1", 3), (1, "I0", 3), (1, "I1", 3)], 6),
+      [(["I0", "I1"], (2, "I0", 3), None), (["I1"], (2, "I1", 3), 6)],
+      slot_of=lambda k: {"I0": 1, "I1": 2}[k], ring_kt=3)
