@@ -193,3 +193,62 @@ def test_overflow_gives_defined_result_not_nan():
         ce, *_ = exact(video[:, ind:ind + 8], q, iters=2, is_online=True)
         assert m.online_ind == exact.online_ind
         assert maxdiff(cs, ce) < 1e-3
+
+
+def test_range_guard_sweep_at_c2_scale():
+    """with no released checkpoint available, sweep synthetic weights whose hidden activations cover
+    ~1e1 ... 1e6 through the FULL predictor at BASELINE configs[1] scale (256x256, T=48, N=400, offline) and record where the
+    split-half back end first leaves the f16 range.  Below that point it must agree with the exact-f32 back end to the
+    parity bar; from that point on the guard must fire and the returned result must be the exact-f32 back end's, bit for bit
+    (the HIP encoder is deterministic, so the re-run reproduces a direct f32 run exactly).  The table goes to
+    gpurun_out/range_sweep_c2.json (copied to profiles/)."""
+    import json
+    import os
+    from cotracker_amd import model as M
+    from cotracker_amd.predictor import CoTrackerPredictor
+    from cotracker_amd.synthetic import synthetic_video
+    from cotracker_amd.weights import fill_synthetic_
+
+    video = synthetic_video(48, 256, 256, seed=1234).to(dev())
+
+    def run(precision, scale):
+        old, M.DEFAULT_PRECISION = M.DEFAULT_PRECISION, precision
+        try:
+            p = CoTrackerPredictor(checkpoint=None, offline=True, window_len=60)
+        finally:
+            M.DEFAULT_PRECISION = old
+        fill_synthetic_(p.model, seed=0)
+        with torch.no_grad():  # hidden = gelu(fc1(x)) grows with `scale`; fc2 undoes it, so the function stays comparable
+            for blk in p.model.updateformer.time_blocks:
+                blk.mlp.fc1.weight.mul_(scale)
+                blk.mlp.fc1.bias.mul_(scale)
+                blk.mlp.fc2.weight.mul_(1.0 / scale)
+        p.model.invalidate_packed_weights()
+        p = p.to(dev())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks, vis = p(video, grid_size=20)
+        vl, cl = p.model.last_logits
+        return tracks.clone(), vl.clone(), cl.clone(), p.model.range_fallbacks
+
+    rows, first = [], None
+    for scale in (1.0, 1e2, 1e3, 3e3, 1e4, 3e4, 1e5, 1e6):
+        t32, v32, c32, fb32 = run("f32", scale)
+        t16, v16, c16, fb16 = run("f16x3", scale)
+        assert fb32 == 0 and torch.isfinite(t32).all()
+        row = {"fc1_scale": scale, "fallback": bool(fb16), "tracks_px": maxdiff(t16, t32), "vis_logit": maxdiff(v16, v32),
+               "conf_logit": maxdiff(c16, c32), "bit_identical_to_f32": bool(torch.equal(t16, t32) and torch.equal(v16, v32))}
+        rows.append(row)
+        if fb16:
+            first = first or scale
+            assert row["bit_identical_to_f32"], row   # the fallback IS the exact-f32 back end
+        else:
+            assert first is None, "the guard fired at a smaller scale but not here"
+            assert row["tracks_px"] < 2e-3 and row["vis_logit"] < 2e-4 and row["conf_logit"] < 2e-4, row
+    assert first is not None, "the sweep never left the f16 range: extend it"
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "range_sweep_c2.json"), "w") as f:
+        json.dump({"workload": "BASELINE configs[1]: 256x256 T=48 N=400 offline, time_blocks[*].mlp.fc1 x scale, fc2 / scale",
+                   "first_fallback_at_scale": first, "rows": rows}, f, indent=1)
+    print(json.dumps(rows))
