@@ -353,9 +353,13 @@ int ctk_gemm(const ctk_gemm_args* g, void* stream);
  *                          pre-scaled by a power of two into [2^13, 2^14) so their own `lo` never underflows;
  *   |x| >= 65504           `hi` overflows to inf, `lo` becomes -inf/NaN, and the non-finite value reaches the window state
  *                          (coords / vis / conf) -- nothing on the path clamps or masks it.  The library itself does not test
- *                          for it; the host models check the finished window state once per forward and re-run that forward on
- *                          the exact-f32 back end (Wp == NULL everywhere) when it is non-finite (cotracker_amd/model.py,
- *                          `range_guard`).  A caller that drives ctk_forward_window directly should do the same.
+ *                          for it; the CoTracker3 host models check the finished window state once per forward and re-run that
+ *                          forward on the exact-f32 back end (Wp == NULL everywhere) when it is non-finite (cotracker_amd/model.py,
+ *                          `range_guard`; with the streaming hipGraph the check is deferred by one call and a hit RAISES instead --
+ *                          INTEGRATION.md).  The CoTracker2 host model (model_v2.py, ctk_forward_window_v2) does NOT check: it is
+ *                          unguarded.  A caller that drives ctk_forward_window directly should do the check itself.  Measured
+ *                          margin on synthetic weights at BASELINE configs[1] scale: the MLP hidden layer has to be scaled by
+ *                          3e4 before the first fallback (profiles/r03_range_sweep_c2.json).
  * The exact-f32 back end (v_mfma_f32_32x32x2_f32, f32 operands in HBM) has the reference's range and ~1/3 of the speed.    */
 int ctk_split_rows(const float* x, int64_t ld, int64_t M, int32_t K, void* out, void* stream);
 int ctk_pack_weight_bytes(int32_t N, int32_t K, size_t* out_bytes);
