@@ -149,9 +149,30 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
   // ---- footprint prefetch into registers: load i of thread (wave w, lane l) = pixel row (4 i + w) * 2 + (l >> 5),
   //      16-byte chunk l & 31 of that pixel's 512 B (K-tile = chunk >> 3)
   f16x8 pre[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) pre[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};  // (rows a path does not load are committed as they are)
+  // Round 3: the generic row -> (fy, fx) decode below costs ~19 VALU per load (float divide emulation, fix-ups, 64-bit
+  // address arithmetic), 44 % of all the VALU instructions this kernel issued per frame.  A footprint is 8 pixels wide
+  // unless a coordinate is an exact integer or the patch hangs over the image border, and then row r = 8 i + 2 wave + half
+  // is simply pixel (fy, fx) = (i, 2 wave + half): one uniform base per load (SALU) plus a per-thread constant offset, i.e.
+  // global_load_dwordx4 v, v_off, s[base] with no VALU at all.  Rows past the footprint (fh < 8) re-read its last ROW
+  // instead of its last pixel; they are never blended.
+  const unsigned lane_off = (unsigned)((2 * wave + (lane >> 5)) * (2 * CTK_C) + (lane & 31) * 8) * 2u;  // bytes
   auto prefetch = [&](int tl) {
     const FrameTab* tab = tabs + tl;
-    const int fw = tab->fw, npx = fw * tab->fh;
+    const int fw = tab->fw, fh = tab->fh, npx = fw * fh;
+    if (fw == 8) {
+      const char* base = reinterpret_cast<const char*>(fm + ((long)(t0 + tl) * H * W + (long)tab->yb * W + tab->xb) * (2 * CTK_C));
+      const long pitch = (long)W * (2 * CTK_C) * 2;  // bytes per pyramid row
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {  // (the same loads are defined as on the generic path: no register shuffling at the join)
+        if (i < 8 || npx > 64) {
+          const char* rowp = base + (long)min(i, fh - 1) * pitch;  // uniform
+          pre[i] = *reinterpret_cast<const f16x8*>(rowp + lane_off);
+        }
+      }
+      return;
+    }
     const _Float16* frame = fm + ((long)(t0 + tl) * H * W + (long)tab->yb * W + tab->xb) * (2 * CTK_C) + (lane & 31) * 8;
     const float rfw = 1.0f / (float)fw;
 #pragma unroll
@@ -214,6 +235,11 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
     const FrameTab* tab = tabs + tl;
     const int fw = tab->fw, npx = fw * tab->fh;
 
+    // Round-3 bisection of this loop (tools/bench_corr.py history, profiles/r03_corr_bisect.txt; us per launch at the C3 window):
+    // full 2822 | no volume stores 2301 | no footprint loads 2430 | no MFMA phase 2346 | no blend 2554 | no C write 2674 |
+    // MFMA phase only 1367 | barriers + commit + split only 774.  The parts ADD: every phase is a short latency chain behind a
+    // barrier and two workgroups per CU (LDS, 250 VGPRs) are all there is to overlap them; a pseudo-random start delay per
+    // workgroup (co-resident workgroups out of phase) changes nothing, and 40 % fewer VALU instructions bought 2 %.
     // (1) footprint registers -> LDS (every reader of the previous frame's C / staging is past the barrier of (5)),
     //     then start fetching the next frame
     commit(npx);
