@@ -13,17 +13,22 @@
 // (scaled by 2^8, exact) so footprints need no per-iteration blend/split arithmetic at all.
 // Products use the split-half scheme of gemm_f16x3.hip (3 x v_mfma_f32_32x32x16_f16, ~2^-21 relative).
 //
-// Workgroup = (point n, level l, <=16 frames), 4 waves, TWO workgroups per CU (LDS 77 KiB each) so that one
-// workgroup's MFMA phase overlaps the other's blend / store phase:
+// Workgroup = (point n, level l, <=16 frames), 4 waves, TWO workgroups per CU (LDS 78 KiB each):
 //   prologue: the chunk's coordinates and all per-frame tap tables go to LDS; the support patch [49][128] is
-//     split once into LDS (K-tile major, XOR-swizzled 16-byte chunks);
-//   per frame: the footprint (<= 81 pixels x 512 B of SH data) is PREFETCHED INTO REGISTERS one frame ahead
-//     (8 or 12 global_load_dwordx4 per thread, 32 lanes per pixel) and written to a single LDS buffer with the
-//     swizzle; wave w = (row tile w>>1, column tile w&1) runs 8 k-steps x 3 MFMAs on two accumulators;
-//     accumulators -> f32 C[pixel][q] in LDS (aliasing the consumed footprint); 245 threads blend 12 (or 1)
-//     consecutive q of one tap p into an f32 staging row; all threads then split 4 consecutive outputs each and
-//     store hi/lo halves into the SH volume row (n*S+t), column p*49+q == the reference's (h,w,i,j)
-//     flattening (:205); columns 2401..2431 (K padding of corr_mlp.fc1) are written as zeros.
+//     split once into LDS (K-tile major, XOR-swizzled 16-byte chunks), read into B-fragment registers, and its LDS is
+//     reused for the C table and the staging row;
+//   the footprint (<= 81 pixels x 512 B of SH data) is PREFETCHED INTO REGISTERS one frame ahead (8 or 12
+//     global_load_dwordx4 per thread, 32 lanes per pixel) and committed to a single LDS buffer with the swizzle;
+//   the frame loop is software-pipelined over TWO barriers per frame (round 3; it was five):
+//     phase A: wave w = (row tile w>>1, column tile w&1) runs 8 k-steps x 3 MFMAs on two accumulators for frame t,
+//              and 245 threads blend frame t-1: 12 (or 1) consecutive q of one tap p from the f32 C table into the f32
+//              staging row;
+//     phase B: accumulators of frame t -> C table; registers of frame t+1 -> footprint buffer, loads of frame t+2 issued;
+//              all threads split 8 staged outputs of frame t-1 each and store whole 128-byte lines of the SH volume row
+//              (n*S+t), column p*49+q == the reference's (h,w,i,j) flattening (:205); columns 2401..2431 (K padding of
+//              corr_mlp.fc1) are zeros.
+//     Footprint, C and staging are separate buffers, so nothing aliases inside the loop and a wave carries MFMA work and
+//     VALU/LDS work of two different frames between the same pair of barriers.
 #include "ctk_common.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
@@ -32,20 +37,23 @@
 namespace {
 
 constexpr int TC = 16;                       // frames per workgroup
-constexpr int FROWS = 96;                    // footprint rows held in LDS (>= 81)
+constexpr int FROWS = 88;                    // footprint rows held in LDS (>= 81; the third MFMA row tile reads 8 rows past it)
 constexpr int NKT = CTK_C / 32;              // 4 K-tiles
 constexpr int SUP_KT = CTK_TAPS * 128;       // bytes per K-tile of the support image: 49 rows x 128 B (rows 49..63 of a
-                                             // 64-row MFMA tile read the next K-tile / the footprint: finite, unused)
+                                             // 64-row MFMA tile read the next K-tile / what follows: unused columns)
 constexpr int SUP_BYTES = NKT * SUP_KT;      // 25088
-constexpr int FP_BYTES = NKT * FROWS * 128;  // 48 KiB  [ktile][96 rows][128 B]; later C [96][68] f32 + staging [2432] f32
+constexpr int FP_BYTES = NKT * FROWS * 128;  // 44 KiB  [ktile][88 rows][128 B]
 constexpr int TAB_BYTES = TC * 256 + 128;    // per-frame tap tables + the chunk's coordinates
-constexpr int CPITCH = 68;                   // floats per C row (16-byte aligned rows for ds_read_b128)
-constexpr int STG_OFF = FROWS * CPITCH * 4;  // 26112: f32 staging row of the blended outputs
+constexpr int CPITCH = 60;                   // floats per C row: 15 sixteen-byte slots, so the five q chunks (3 slots apart) of
+                                             // three neighbouring pixel rows land in 15 different slots of a ds_read_b128 group
+constexpr int C_BYTES = FROWS * CPITCH * 4;  // 21120: f32 C[pixel][q] (columns 0..48 are written)
+constexpr int STG_BYTES1 = CTK_CORR_LD * 4;  // 9728: f32 staging row of the blended outputs
 constexpr float FSCALE = 256.0f;             // both operands are scaled by 2^8 before the f16 split
 constexpr float UNSCALE = 1.0f / 65536.0f;
 constexpr int QUADS = CTK_CORR_LD / 4;       // 608 output quads per (frame, level, point)
-static_assert(STG_OFF + CTK_CORR_LD * 4 <= FP_BYTES, "C + staging must fit in the footprint buffer");
-static_assert(2 * (SUP_BYTES + FP_BYTES + TAB_BYTES) <= 160 * 1024, "two workgroups per CU");
+constexpr int LDS1_BYTES = FP_BYTES + C_BYTES + STG_BYTES1 + TAB_BYTES;  // 80128
+static_assert(SUP_BYTES + 15 * 128 <= C_BYTES + STG_BYTES1, "the support image (prologue only) aliases C + staging");
+static_assert(2 * LDS1_BYTES <= 160 * 1024, "two workgroups per CU");
 
 struct CorrShP {
   const _Float16* fm[CTK_LEVELS];  // SH pyramid of the window: [S][H][W][4][2][32] halves, scaled by 2^8
@@ -69,11 +77,13 @@ struct FrameTab {  // per-frame tap table (LDS), 256 bytes
 static_assert(sizeof(FrameTab) == 256, "FrameTab layout");
 
 __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[SUP_BYTES + FP_BYTES + TAB_BYTES];
-  unsigned char* sup = lds;
-  unsigned char* fp = lds + SUP_BYTES;
-  FrameTab* tabs = reinterpret_cast<FrameTab*>(lds + SUP_BYTES + FP_BYTES);
-  float* cxy = reinterpret_cast<float*>(lds + SUP_BYTES + FP_BYTES + TC * 256);  // [TC][2]
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS1_BYTES];
+  unsigned char* fp = lds;
+  float* C = reinterpret_cast<float*>(lds + FP_BYTES);
+  float* stg = reinterpret_cast<float*>(lds + FP_BYTES + C_BYTES);
+  unsigned char* sup = lds + FP_BYTES;  // prologue only (aliases C + staging)
+  FrameTab* tabs = reinterpret_cast<FrameTab*>(lds + FP_BYTES + C_BYTES + STG_BYTES1);
+  float* cxy = reinterpret_cast<float*>(lds + FP_BYTES + C_BYTES + STG_BYTES1 + TC * 256);  // [TC][2]
 
   unsigned bid = ctk_xcd_remap(blockIdx.x, gridDim.x);
   const int tc = bid % p.tchunks;
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
       if (i < 8 || npx > 64) {
         const int r = (4 * i + wave) * 2 + (lane >> 5);
         const int cc = lane & 31, kt = cc >> 3, c = cc & 7;
-        *reinterpret_cast<f16x8*>(fp + kt * (FROWS * 128) + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = pre[i];
+        if (i < 11 || r < FROWS) *reinterpret_cast<f16x8*>(fp + kt * (FROWS * 128) + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = pre[i];
       }
     }
   };
@@ -231,23 +241,27 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
   const int bwy = bp / 7, bhx = bp - bwy * 7;
   const int bpo = bhx * 7 + bwy;  // the tap's column block in the volume row
 
-  for (int tl = 0; tl < nt; ++tl) {
-    const FrameTab* tab = tabs + tl;
-    const int fw = tab->fw, npx = fw * tab->fh;
+  // every wave has its B fragments: the support image's LDS becomes C + staging
+  __syncthreads();
+  if (tid < CTK_CORR_LD - CTK_CORR_K) stg[CTK_CORR_K + tid] = 0.0f;  // K padding columns (never touched by the blend)
+  commit(tabs[0].fw * tabs[0].fh);
+  if (1 < nt) prefetch(1);
+  __syncthreads();
 
-    // Round-3 bisection of this loop (tools/bench_corr.py history, profiles/r03_corr_bisect.txt; us per launch at the C3 window):
-    // full 2822 | no volume stores 2301 | no footprint loads 2430 | no MFMA phase 2346 | no blend 2554 | no C write 2674 |
-    // MFMA phase only 1367 | barriers + commit + split only 774.  The parts ADD: every phase is a short latency chain behind a
-    // barrier and two workgroups per CU (LDS, 250 VGPRs) are all there is to overlap them; a pseudo-random start delay per
-    // workgroup (co-resident workgroups out of phase) changes nothing, and 40 % fewer VALU instructions bought 2 %.
-    // (1) footprint registers -> LDS (every reader of the previous frame's C / staging is past the barrier of (5)),
-    //     then start fetching the next frame
-    commit(npx);
-    if (tl + 1 < nt) prefetch(tl + 1);
-    __syncthreads();
+  // Bisection of the five-barrier loop this one replaces (profiles/r03_corr_bisect.txt; us per launch at the C3 window):
+  // full 2822 | no volume stores 2301 | no footprint loads 2430 | no MFMA phase 2346 | no blend 2554 | no C write 2674 |
+  // MFMA phase only 1367 | barriers + commit + split only 774.  The parts ADDED UP: every phase was a short latency chain
+  // behind its own barrier with two workgroups per CU to overlap them; a pseudo-random start delay per workgroup changed
+  // nothing and 40 % fewer VALU instructions bought 2 %.  Hence fewer, fatter phases.
+  f32x16 acc0, acc1;
+  for (int tl = 0; tl <= nt; ++tl) {
+    const bool cur = tl < nt, prev = tl >= 1;
+    const FrameTab* tab = tabs + min(tl, nt - 1);
+    const bool third = cur && tab->fw * tab->fh > 64 && wave < 2;
 
-    // (2) C[pixel][q] for my (row tile, column tile); a rare 9-wide footprint has a third row tile (waves 0,1).
-    //     Two accumulators (even / odd K-tiles) halve the dependent-MFMA chain.
+    // ---- phase A ------------------------------------------------------------------------------------------
+    // (A1) C[pixel][q] of frame tl for my (row tile, column tile); a rare 9-wide footprint has a third row tile
+    //      (waves 0,1).  Two accumulators (even / odd K-tiles) halve the dependent-MFMA chain.
     auto mma_tile = [&](int row0, f32x16& acc) {
       const unsigned char* arow = fp + (row0 + r32) * 128;
       f32x16 acc_b;
@@ -275,28 +289,18 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
         }
       acc += acc_b;
     };
-    const bool third = npx > 64 && wave < 2;
-    f32x16 acc0, acc1;
-    mma_tile(rtile * 32, acc0);
-    if (third) mma_tile(64, acc1);
-
-    // (3) everyone is done reading the footprint -> overwrite it with C (f32, [96][68])
-    __syncthreads();
-    float* C = reinterpret_cast<float*>(fp);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // row inside the 32x32 tile
-      C[(rtile * 32 + i) * CPITCH + ctile * 32 + r32] = acc0[reg] * UNSCALE;
-      if (third) C[(64 + i) * CPITCH + ctile * 32 + r32] = acc1[reg] * UNSCALE;
+    if (cur) {
+      mma_tile(rtile * 32, acc0);
+      if (third) mma_tile(64, acc1);
     }
-    __syncthreads();
 
-    // (4) bilinear blend of the 49x49 table: D[p][q] = sum over the 4 corners of w * C[corner pixel][q]
-    //     (corner order and weight products of ATen grid_sampler_3d: (x0,y0),(x1,y0),(x0,y1),(x1,y1))
-    float* stg = reinterpret_cast<float*>(fp + STG_OFF);
-    if (bcnt > 0) {
-      const int x0 = tab->fx0[bhx], x1 = tab->fx1[bhx], y0 = tab->fy0[bwy], y1 = tab->fy1[bwy];
-      const float wx0 = tab->wx0[bhx], wx1 = tab->wx1[bhx], wy0 = tab->wy0[bwy], wy1 = tab->wy1[bwy];
+    // (A2) bilinear blend of frame tl-1's 49x49 table: D[p][q] = sum over the 4 corners of w * C[corner pixel][q]
+    //      (corner order and weight products of ATen grid_sampler_3d: (x0,y0),(x1,y0),(x0,y1),(x1,y1))
+    if (prev && bcnt > 0) {
+      const FrameTab* tb = tabs + (tl - 1);
+      const int fw = tb->fw;
+      const int x0 = tb->fx0[bhx], x1 = tb->fx1[bhx], y0 = tb->fy0[bwy], y1 = tb->fy1[bwy];
+      const float wx0 = tb->wx0[bhx], wx1 = tb->wx1[bhx], wy0 = tb->wy0[bwy], wy1 = tb->wy1[bwy];
       const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
       const float* c00 = C + (y0 * fw + x0) * CPITCH + bq0;
       const float* c10 = C + (y0 * fw + x1) * CPITCH + bq0;
@@ -315,21 +319,45 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
         dst[0] = fmaf(c11[0], w11, fmaf(c01[0], w01, fmaf(c10[0], w10, c00[0] * w00)));
       }
     }
-    if (tid < CTK_CORR_LD - CTK_CORR_K) stg[CTK_CORR_K + tid] = 0.0f;  // K padding columns
     __syncthreads();
 
-    // (5) staging row -> SH volume row: 4 consecutive outputs per thread, hi / lo halves
-    // Round 3: FULL 128-byte lines per 8 lanes.  A CU retires a store instruction only every ~100 cycles whatever its width
-    // (tools/gemm_lab.cpp store experiments), and the 8-byte hi / lo pieces of round 2 were 24 wave-instructions per frame;
-    // lane (line, chunk c) now writes 16 bytes -- hi halves of 8 outputs for c < 4, their lo halves for c >= 4 (both lanes of
-    // an octet split the same 8 values) -- 76 lines x 8 lanes = 10 wave-instructions per frame, each a run of whole lines.
-    _Float16* orow = out_base + (long)tl * ROW_H;
-    for (int idx = tid; idx < (CTK_CORR_LD / 32) * 8; idx += 256) {
-      const int line = idx >> 3, c = idx & 7, oct = line * 4 + (c & 3);
-      f16x8 hi, lo;
-      ctk_split8(reinterpret_cast<const f32x4*>(stg)[2 * oct], reinterpret_cast<const f32x4*>(stg)[2 * oct + 1], hi, lo);
-      *reinterpret_cast<f16x8*>(orow + line * 64 + c * 8) = (c < 4) ? hi : lo;
+    // ---- phase B ------------------------------------------------------------------------------------------
+    // (B1) accumulators of frame tl -> C (f32, [88][60]; the 49 tap columns only)
+    if (cur && ctile * 32 + r32 < CTK_TAPS) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // row inside the 32x32 tile
+        C[(rtile * 32 + i) * CPITCH + ctile * 32 + r32] = acc0[reg] * UNSCALE;
+        if (third && i < FROWS - 64) C[(64 + i) * CPITCH + ctile * 32 + r32] = acc1[reg] * UNSCALE;
+      }
     }
+    // (B2) footprint of frame tl+1: registers -> LDS (its loads are the youngest memory operations of this wave, so the
+    //      wait does not cover the stores below); (B4) then fetch frame tl+2
+    if (tl + 1 < nt) commit(tabs[tl + 1].fw * tabs[tl + 1].fh);
+    // (B3) staging row of frame tl-1 -> SH volume row: FULL 128-byte lines per 8 lanes.  A CU retires a store instruction only
+    //      every ~100 cycles whatever its width (tools/gemm_lab.cpp store experiments): lane (line, chunk c) writes 16 bytes --
+    //      hi halves of 8 outputs for c < 4, their lo halves for c >= 4 (both lanes of an octet split the same 8 values) --
+    //      76 lines x 8 lanes = 10 wave-instructions per frame, each a run of whole lines.
+    if (prev) {
+      _Float16* orow = out_base + (long)(tl - 1) * ROW_H;
+      constexpr int NIDX = (CTK_CORR_LD / 32) * 8;  // 608 sixteen-byte pieces = 2 full rounds of the workgroup + 96 threads
+      f32x4 va[3], vb[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {  // all staging reads first (one LDS round trip instead of three)
+        const int idx = min(tid + 256 * k, NIDX - 1), oct = (idx >> 3) * 4 + (idx & 3);
+        va[k] = reinterpret_cast<const f32x4*>(stg)[2 * oct];
+        vb[k] = reinterpret_cast<const f32x4*>(stg)[2 * oct + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = tid + 256 * k, line = idx >> 3, c = idx & 7;
+        if (k == 2 && wave >= 2) break;  // the last 96 pieces belong to waves 0 and 1
+        f16x8 hi, lo;
+        ctk_split8(va[k], vb[k], hi, lo);
+        if (idx < NIDX) *reinterpret_cast<f16x8*>(orow + line * 64 + c * 8) = (c < 4) ? hi : lo;
+      }
+    }
+    if (tl + 2 < nt) prefetch(tl + 2);
     __syncthreads();
   }
 }
