@@ -19,7 +19,7 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -168,6 +168,8 @@ SYMBOLS = {
     "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
     "ctk_profile_enable": (C.c_int, [C.c_int]),
     "ctk_gemm_pp_mode": (None, [C.c_int]),
+    "ctk_gemm_scratch_bytes": (C.c_int, [_P(C.c_size_t)]),
+    "ctk_gemm_set_scratch": (C.c_int, [C.c_void_p, C.c_size_t, _fp]),
     "ctk_profile_read": (C.c_int, [_P(ProfileRow), C.c_int, _P(C.c_int)]),
     "ctk_probe_mfma": (C.c_int, [C.c_int, C.c_int, _fp, _P(C.c_double), _fp]),
 }

@@ -2,6 +2,7 @@
 // -> heads + state update, all enqueued on the caller's stream (no host sync, capturable).
 #include "ctk_common.h"
 #include "ctk_profile.h"
+#include "gemm_params.h"
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -143,6 +144,8 @@ struct UfWs {
   float* att;     // [R,384]
   float* hid;     // [R,1536]
   float* partial; // attention split-K partials
+  void* sk;       // stream-K scratch of the persistent GEMMs (gemm_pp.hip): flags + one accumulator tile per CU
+  size_t sk_bytes;
   size_t bytes;
 };
 
@@ -170,6 +173,8 @@ UfWs carve_uf(int S, int N, void* base) {
   w.att = take(R * CTK_HID);
   w.hid = take(R * CTK_MLP);
   w.partial = take((size_t)v2p_splits(N) * S * CTK_HEADS * CTK_VIRT * (CTK_HEAD_DIM + 2));
+  w.sk_bytes = ctk_pp_scratch_bytes();
+  w.sk = take((w.sk_bytes + 3) / 4);
   w.bytes = off;
   return w;
 }
@@ -457,6 +462,7 @@ extern "C" int ctk_update_former(int32_t S, int32_t N, const float* x, const ctk
   const UfWs ws = carve_uf(S, N, workspace);
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  CtkPPScratchScope sk(ws.sk, ws.sk_bytes, s);
   CTK_TRY(input_projection(S, N, x, false, w, ws, s));
   CTK_TRY(run_transformer(S, N, former_of(w), ws, s));
   return ctk_launch_heads(ws.tokens, w->head_w, w->head_b, S, N, delta, nullptr, nullptr, nullptr, s);
@@ -484,6 +490,7 @@ extern "C" int ctk_update_former_ex(int32_t S, int32_t N, const void* x, int32_t
   const UfWs ws = carve_uf(S, N, workspace);
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  CtkPPScratchScope sk(ws.sk, ws.sk_bytes, s);
   // tokens = input_transform(x) (+ per-frame bias rows = W e_t + b when in_bias_t is given, else + in_b)
   CTK_TRY(gemm(static_cast<const float*>(x), w->in_ld, N * S, WRef{w->in_w, w->in_p}, w->in_ld, CTK_HID, w->in_ld, ws.tokens, CTK_HID,
                w->in_bias_t ? nullptr : w->in_b, CTK_ACT_NONE, nullptr, 0, s, w->in_bias_t, S, 1, 0, 0, w->in_dim, x_split != 0, false));
@@ -555,6 +562,7 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
   const CorrWs cws = carve_corr(a, base + off);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool sp = split_mode(w);  // split mode: the transformer input x is kept in SH format
+  CtkPPScratchScope sk(uws.sk, uws.sk_bytes, s);  // every large Linear of the window runs on s, one at a time
   if (sp && a->iters > 0) CTK_TRY(prepare_pyramid_sh(a, cws, s));
   for (int it = 0; it < a->iters; ++it) {                       // cotracker3_online.py:187
     CTK_TRY(run_corr_embed(a, w, x, sp, cws, s));               // :190-210

@@ -57,9 +57,22 @@ struct CtkGemmP {
   int batch; long a_bs; long c_bs;  // batch strides, in elements of the respective format (floats / halves)
   int a_split, c_split;
   int mblocks, nblocks;
+  void* sk;                         // gemm_pp.hip: stream-K scratch (partials + flags) or null; set by the launcher
 };
 
 // gemm_f16x3.hip
 int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s);
 // gemm_pp.hip: persistent ping-pong kernels; returns -1 when the shape is not theirs (caller falls back)
 int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s);
+// Stream-K scratch of the persistent kernels: the entry points that own a workspace lend a piece of it for the duration of
+// the call (thread-local; zeroes the flags on `s`).  Only launches on that stream use it; without one the kernels deal whole
+// tiles in rounds.
+size_t ctk_pp_scratch_bytes();
+struct CtkPPScratchScope {
+  CtkPPScratchScope(void* mem, size_t bytes, hipStream_t s);
+  ~CtkPPScratchScope();
+  CtkPPScratchScope(const CtkPPScratchScope&) = delete;
+  CtkPPScratchScope& operator=(const CtkPPScratchScope&) = delete;
+ private:
+  void* prev_mem_; size_t prev_bytes_; hipStream_t prev_stream_;
+};

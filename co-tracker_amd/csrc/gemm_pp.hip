@@ -25,33 +25,91 @@
 namespace {
 
 // ---- tile walk -----------------------------------------------------------------------------------
-// Persistent workgroup b of G walks over rounds r = 0, 1, ...: in round r the G (or fewer) tiles [r*G, r*G + n_r) are dealt
-// so that XCD x (workgroup b sits on XCD b % 8) gets a contiguous run of logical tiles (neighbours share A rows / W in its L2).
+// Two ways to deal the tiles to the G persistent workgroups:
+//  * rounds (no scratch memory): in round r the G (or fewer) tiles [r*G, r*G + n_r) are dealt so that XCD x (workgroup b sits
+//    on XCD b % 8) gets a contiguous run of logical tiles (neighbours share A rows / W in its L2).  800 tiles on 256 CUs
+//    (every N = 384 Linear of the model at C3) are then FOUR rounds with the last one 1/8 full: 22 % of the launch idles;
+//  * stream-K (CtkGemmP::sk != null): the tiles' K-tiles form one stream of tiles * KT units and workgroup c (logical index,
+//    XCD-contiguous) takes units [c*UT/G, (c+1)*UT/G) -- whole tiles in the middle, the TAIL K-tiles of a tile at its start
+//    and the HEAD K-tiles of a tile at its end (UT/G >= KT, so a tile is shared by at most two workgroups).  The workgroup
+//    that starts inside a tile computes its part first, stores the raw accumulators to its scratch slot and raises one flag
+//    per wave; its logical predecessor reaches the head part of that tile last, adds the stored part in a fixed order
+//    (head + tail: deterministic) and runs the normal epilogue.  Nobody waits for anything produced later than the first
+//    segment of another workgroup, and all G <= #CUs workgroups are resident (one per CU: PP_LDS_ALL), so the spin cannot
+//    deadlock.  The partial costs 192-256 KiB of stores and loads per workgroup against 7/8 of a tile time saved.
+//    MEASURED (tools/gemm_lab quant, profiles/r03_gemm_lab_streamk.txt): the last round is cheaper than it looks -- 32 workgroups
+//    alone on the chip run at boost clocks without contention, mlp.fc2 takes 350 us for 768 tiles, 414 us for 800 (+64, not
+//    +117) and 448 us for 1024 -- so the prize is 12 % of mlp.fc2 and 15 % of the K = 384 Linears at most, of which the
+//    exchange (~20 us: cache-bypassing stores, the consumer's exposed load latency) leaves -5 % for mlp.fc2 (414 -> 394 us)
+//    and nothing for K = 384 (115 -> 118 us).  That is ~0.8 % of a C3 step, below the box-to-box spread of the benchmark,
+//    and it brings a spin-wait into the hottest kernels: OFF unless ctk_gemm_pp_mode bit 4 is set (tests/test_gpu_gemm_pp.py
+//    keeps it correct).
+constexpr int PP_SK_FLAG_BYTES = 16384;    // 8 flags x up to 512 workgroups
+constexpr long PP_SK_SLOT_MAX = 262144;    // 256 x 256 f32 accumulators
+
 struct PPTile {
   const unsigned char* a;  // A rows of the tile, K-tile 0 (bytes)
   const unsigned char* w;  // W rows of the tile, K-tile 0
   int m0, n0, bz;
   unsigned lim;            // last valid row inside the tile (rows beyond M are clamped, never stored)
+  int kb, ke;              // K-tiles [kb, ke) of this tile are mine
+};
+
+struct PPWalk {
+  int tiles_total, KT;
+  int sk;                                 // stream-K walk
+  int t_first, kb_first, t_last, ke_last;  // stream-K: my tiles, where the first starts and the last ends
+  int slot;                                // my logical workgroup index
 };
 
 template <int BM, int BN>
-__device__ __forceinline__ bool pp_tile(const CtkGemmP& g, int tiles_total, int q, PPTile& t) {
-  const int G = gridDim.x, b = blockIdx.x;
-  const int first = q * G;
-  if (first >= tiles_total) return false;
-  const int n_r = min(G, tiles_total - first);
-  if (b >= n_r) return false;
-  unsigned tile = first + ctk_xcd_remap(b, n_r);
+__device__ __forceinline__ void pp_tile_at(const CtkGemmP& g, unsigned tile, const int KT, PPTile& t) {
   const int nb = tile % g.nblocks;
   tile /= g.nblocks;
   const int mb = tile % g.mblocks;
   t.bz = tile / g.mblocks;
   t.m0 = mb * BM;
   t.n0 = nb * BN;
-  const int KT = g.K / 32;
   t.a = reinterpret_cast<const unsigned char*>(g.A) + ((long)t.bz * g.a_bs + (long)t.m0 * g.lda) * 2;
   t.w = reinterpret_cast<const unsigned char*>(g.Wp) + PP_HDR_BYTES + (long)t.n0 * KT * 128;
   t.lim = (unsigned)min(BM - 1, g.M - 1 - t.m0);
+}
+
+__device__ __forceinline__ PPWalk pp_walk_init(const CtkGemmP& g, const int tiles_total, const int KT, const bool sk_ok) {
+  PPWalk w;
+  w.tiles_total = tiles_total;
+  w.KT = KT;
+  w.sk = sk_ok && g.sk != nullptr;
+  const int G = gridDim.x;
+  w.slot = (int)ctk_xcd_remap(blockIdx.x, G);
+  const long UT = (long)tiles_total * KT;
+  const long u0 = UT * w.slot / G, u1 = UT * (w.slot + 1) / G;
+  w.t_first = (int)(u0 / KT);
+  w.kb_first = (int)(u0 - (long)w.t_first * KT);
+  w.t_last = (int)((u1 - 1) / KT);
+  w.ke_last = (int)(u1 - (long)w.t_last * KT);
+  return w;
+}
+
+// q-th tile of this workgroup's walk
+template <int BM, int BN>
+__device__ __forceinline__ bool pp_tile(const CtkGemmP& g, const PPWalk& w, int q, PPTile& t) {
+  if (w.sk) {
+    const int ti = w.t_first + q;
+    if (ti > w.t_last) return false;
+    pp_tile_at<BM, BN>(g, (unsigned)ti, w.KT, t);
+    t.kb = q == 0 ? w.kb_first : 0;
+    t.ke = ti == w.t_last ? w.ke_last : w.KT;
+    return true;
+  }
+  const int G = gridDim.x, b = blockIdx.x;
+  const int first = q * G;
+  if (first >= w.tiles_total) return false;
+  const int n_r = min(G, w.tiles_total - first);
+  if (b >= n_r) return false;
+  pp_tile_at<BM, BN>(g, first + ctk_xcd_remap(b, n_r), w.KT, t);
+  t.kb = 0;
+  t.ke = w.KT;
   return true;
 }
 
@@ -61,25 +119,75 @@ struct PPCursor {
   const unsigned char* a;
   const unsigned char* w;
   unsigned lim;
-  int q, kt;
+  int q, kt, ke;
 };
 
+__device__ __forceinline__ PPCursor pp_cursor_at(const PPTile& t) {
+  return PPCursor{t.a + t.kb * 128, t.w + t.kb * 128, t.lim, 0, t.kb, t.ke};
+}
+
 template <int BM, int BN>
-__device__ __forceinline__ void pp_cursor_next(const CtkGemmP& g, int tiles_total, int KT, PPCursor& c) {
-  if (c.kt + 1 < KT) {
+__device__ __forceinline__ void pp_cursor_next(const CtkGemmP& g, const PPWalk& w, PPCursor& c) {
+  if (c.kt + 1 < c.ke) {
     c.kt += 1;
     c.a += 128;
     c.w += 128;
   } else {
     PPTile t;
-    if (pp_tile<BM, BN>(g, tiles_total, c.q + 1, t)) {
+    if (pp_tile<BM, BN>(g, w, c.q + 1, t)) {  // (only the first tile of a walk starts past K-tile 0)
       c.q += 1;
       c.kt = 0;
+      c.ke = t.ke;
       c.a = t.a;
       c.w = t.w;
       c.lim = t.lim;
     }
   }
+}
+
+// ---- stream-K partials ---------------------------------------------------------------------------
+// Scratch layout: [PP_SK_FLAG_BYTES of flags: 8 per workgroup, one per wave][G slots of PP_SK_SLOT_MAX bytes].  A slot holds
+// the partial TILE, row-major f32 with a pitch of BN floats and already multiplied by 1/s (no bias): it is written by the
+// ordinary epilogue (pp_epilogue_io routed to the slot) and added by the ordinary epilogue of the owner.  Wave w of the
+// consumer reads exactly the elements wave w of the producer wrote (same wave tile), so each wave has its own flag and no
+// workgroup barrier is needed in the epilogue.  Only the kernels whose epilogue is linear with an f32 output take part.
+constexpr bool pp_sk_epi(int EPI) { return (EPI & 3) == 0 && (EPI & 8) == 0 && (EPI & 16) == 0 && (EPI & 32) != 0; }
+
+__device__ __forceinline__ unsigned char* pp_sk_slot(const CtkGemmP& g, const int slot) {
+  return static_cast<unsigned char*>(g.sk) + PP_SK_FLAG_BYTES + (long)slot * PP_SK_SLOT_MAX;
+}
+__device__ __forceinline__ int* pp_sk_flag(const CtkGemmP& g, const int slot, const int wave) { return static_cast<int*>(g.sk) + slot * 8 + wave; }
+
+// Epilogue of tile `done` under the walk: routes the output (see PPEpiIO), waits for / raises the flags.
+template <int EPI, int BM, int BN, int MI, int NI, class RowOf, class ColOf>
+__device__ __forceinline__ void pp_walk_epilogue(const CtkGemmP& g, const PPWalk& w, const PPTile& done, f32x16 (&acc)[MI][NI], const int lane, const int wave,
+                                                 const float unscale, const float* bias_lds, unsigned char* scratch,
+                                                 RowOf row_of, ColOf col_of, const bool no_store) {
+  if (!pp_sk_epi(EPI)) {
+    pp_epilogue<EPI, MI, NI>(g, acc, lane, done.bz, unscale, bias_lds, scratch, row_of, col_of, no_store);
+    return;
+  }
+  const bool part = done.kb > 0;          // tail K-tiles of a tile my logical predecessor finishes: result -> my slot
+  const bool fix = done.ke < w.KT;        // head K-tiles of a tile whose tail my logical successor computed first
+  const long tile_off = ((long)done.m0 * BN + done.n0) * 4;  // row_of / col_of are matrix coordinates: slots are addressed through them
+  PPEpiIO io;
+  io.c = part ? pp_sk_slot(g, w.slot) - tile_off : static_cast<unsigned char*>(g.C) + (long)done.bz * g.c_bs * 4;
+  io.ldc = part ? BN : g.ldc;
+  io.M = part ? done.m0 + BM : g.M;
+  io.add = fix ? pp_sk_slot(g, w.slot + 1) - tile_off : nullptr;
+  io.add_ld = BN;
+  io.bias_scale = part ? 0.0f : 1.0f;
+  io.through = part;
+  if (fix) {  // (relaxed system-scope poll = a load that misses every cache; the tile loads behind it bypass the caches too)
+    int* flag = pp_sk_flag(g, w.slot + 1, wave);
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) __builtin_amdgcn_s_sleep(8);
+  }
+  pp_epilogue_io<EPI, MI, NI>(g, io, acc, lane, unscale, bias_lds, scratch, row_of, col_of, no_store);
+  if (part) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every write-through store of this wave has been acknowledged
+    if (lane == 0) __hip_atomic_store(pp_sk_flag(g, w.slot, wave), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (fix && lane == 0) __hip_atomic_store(pp_sk_flag(g, w.slot + 1, wave), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // free for the next launch
 }
 
 // ================================================================================================
@@ -110,8 +218,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   const int wm = wave >> 2, wn = wave & 3;
   const int r32 = lane & 31, half = lane >> 5;
 
+  const PPWalk walk = pp_walk_init(g, tiles_total, KT, pp_sk_epi(EPI));
   PPTile tile;
-  if (!pp_tile<BM, BN>(g, tiles_total, 0, tile)) return;
+  if (!pp_tile<BM, BN>(g, walk, 0, tile)) return;
   const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
   const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
   pp_stage_bias<EPI>(g, lds + RING, tid);
@@ -184,7 +293,8 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   auto scratch = [&]() { return grp == 0 ? lds + RING + PP_BIAS_BYTES + wave * 4096 : lds + (par ^ 1) * 32768 + 16384 + (wave & 3) * 4096; };
   PPResid<4, 2> resid;
   auto resid_issue = [&]() { pp_resid_issue<EPI, 4, 2>(g, resid, lane, tile.bz, row_of, col_of); };
-  auto init_acc = [&]() { pp_init_acc<EPI, 4, 2>(acc, resid, lane, w_scale, scratch()); };
+  // (a workgroup that starts in the middle of a tile contributes K-tiles only: its accumulators start from 0 x residual)
+  auto init_acc = [&](const float sc) { pp_init_acc<EPI, 4, 2>(acc, resid, lane, sc, scratch()); };
   // operands swapped on purpose (D'[n][m]: lane = output row, register quad = 4 consecutive columns); small terms first
   auto mma = [&](const int a, const int b) {
     __builtin_amdgcn_s_setprio(1);
@@ -202,26 +312,26 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   // ---- stream set-up: blocks 0..5 = K-tile 0 (all four) + K-tile 1 (A_0, B_0)
   PPCursor c1, c2;  // K-tiles J+1 and J+2 of the stream
   {
-    PPCursor c0{tile.a, tile.w, tile.lim, 0, 0};
+    PPCursor c0 = pp_cursor_at(tile);
     dma_a(c0, 0, 0);
     dma_b(c0, 0, 0);
     dma_b(c0, 1, 0);
     dma_a(c0, 1, 0);
     c1 = c0;
-    pp_cursor_next<BM, BN>(g, tiles_total, KT, c1);
+    pp_cursor_next<BM, BN>(g, walk, c1);
     dma_a(c1, 0, 1);
     dma_b(c1, 0, 1);
     c2 = c1;
-    pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+    pp_cursor_next<BM, BN>(g, walk, c2);
   }
   resid_issue();
-  init_acc();
+  init_acc(tile.kb > 0 ? 0.0f : w_scale);
   PP_WAIT_VM(8);   // blocks 0, 1 (K-tile 0: A_0, B_0) have landed
   PP_BARRIER();
   if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one barrier behind group 0
 
   for (int q = 0;; ++q) {  // my tiles
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = tile.kb; kt < tile.ke; ++kt) {
       // ---- phase 0 (a=0, b=0): read A_0, B_0; issue B_1 of K-tile J+1
       read_a(0);
       read_b(0);
@@ -250,13 +360,13 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
       // ---- phase 3 (a=1, b=0): nothing to read (B_0 is still in registers); issue B_0 of K-tile J+2
       dma_b(c2, 0, par);
       PP_WAIT_VM(8);
-      const bool last = kt + 1 == KT;
+      const bool last = kt + 1 == tile.ke;
       PP_BARRIER();
       mma(1, 0);
       if (!last) PP_BARRIER();
       // advance the stream
       c1 = c2;
-      pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+      pp_cursor_next<BM, BN>(g, walk, c2);
       par ^= 1;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -272,12 +382,12 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
     // the next tile's residual is requested BEFORE this tile's epilogue (it lands behind the epilogue's arithmetic and stores);
     // the epilogue therefore works on a copy of the tile descriptor
     const PPTile done = tile;
-    const bool more = pp_tile<BM, BN>(g, tiles_total, q + 1, tile);
+    const bool more = pp_tile<BM, BN>(g, walk, q + 1, tile);
     resid_issue();  // unconditional (on the last tile it re-reads valid addresses; a conditional re-init doubles the live accumulators)
-    pp_epilogue<EPI, 4, 2>(g, acc, lane, done.bz, w_unscale, bias_lds, scratch(),
-                           [&](int i) { return done.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; }, [&](int b) { return done.n0 + wn * 32 + b * 128; },
-                           (dbg & 2) != 0);
-    init_acc();
+    pp_walk_epilogue<EPI, BM, BN, 4, 2>(g, walk, done, acc, lane, wave, w_unscale, bias_lds, scratch(),
+                                        [&](int i) { return done.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; }, [&](int b) { return done.n0 + wn * 32 + b * 128; },
+                                        (dbg & 2) != 0);
+    init_acc(w_scale);
     if (grp == 1) PP_BARRIER();
     if (!more) break;
   }
@@ -311,8 +421,9 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, half = lane >> 5;
 
+  const PPWalk walk = pp_walk_init(g, tiles_total, KT, pp_sk_epi(EPI));
   PPTile tile;
-  if (!pp_tile<BM, BN>(g, tiles_total, 0, tile)) return;
+  if (!pp_tile<BM, BN>(g, walk, 0, tile)) return;
   const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
   const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
   pp_stage_bias<EPI>(g, lds + RING, tid);
@@ -389,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   auto col_of = [&](int ni) { return tile.n0 + wn * 32 + ni * 64; };
   PPResid<2, 3> resid;
   auto resid_issue = [&]() { pp_resid_issue<EPI, 2, 3>(g, resid, lane, tile.bz, row_of, col_of); };
-  auto init_acc = [&]() { pp_init_acc<EPI, 2, 3>(acc, resid, lane, w_scale, lds + RING + PP_BIAS_BYTES + wave * 4096); };
+  auto init_acc = [&](const float sc) { pp_init_acc<EPI, 2, 3>(acc, resid, lane, sc, lds + RING + PP_BIAS_BYTES + wave * 4096); };
   auto mma = [&](const int n) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -405,18 +516,18 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   // ---- stream set-up: blocks 0..3 = K-tile 0 (I0, I1, I2) + I0 of K-tile 1
   PPCursor c1, c2;
   {
-    PPCursor c0{tile.a, tile.w, tile.lim, 0, 0};
+    PPCursor c0 = pp_cursor_at(tile);
     issue_i0(c0, 0);
     issue_i1(c0, 0);
     issue_i2(c0, 0);
     c1 = c0;
-    pp_cursor_next<BM, BN>(g, tiles_total, KT, c1);
+    pp_cursor_next<BM, BN>(g, walk, c1);
     issue_i0(c1, 1);
     c2 = c1;
-    pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+    pp_cursor_next<BM, BN>(g, walk, c2);
   }
   resid_issue();
-  init_acc();
+  init_acc(tile.kb > 0 ? 0.0f : w_scale);
   set_rd(0);
   PP_WAIT_VM(5);  // I0, I1 of K-tile 0 landed (I2: 2 pieces and I0 of K-tile 1: 3 pieces may be in flight)
   PP_BARRIER();
@@ -424,7 +535,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
 
   int par = 0;
   for (int q = 0;; ++q) {
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = tile.kb; kt < tile.ke; ++kt) {
       // ---- phase 0: read A, B_0; issue I1 of K-tile J+1; wait for I2 of this K-tile
       read_a();
       read_b(0);
@@ -445,23 +556,23 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
       read_b(2);
       issue_i0(c2, par);
       PP_WAIT_VM(5);
-      const bool last = kt + 1 == KT;
+      const bool last = kt + 1 == tile.ke;
       PP_BARRIER();
       PP_WAIT_LGKM0();
       mma(2);
       if (!last) PP_BARRIER();
       c1 = c2;
-      pp_cursor_next<BM, BN>(g, tiles_total, KT, c2);
+      pp_cursor_next<BM, BN>(g, walk, c2);
       par ^= 1;
       set_rd(par);
     }
     if (grp == 0) PP_BARRIER();
     const PPTile done = tile;
-    const bool more = pp_tile<BM, BN>(g, tiles_total, q + 1, tile);
+    const bool more = pp_tile<BM, BN>(g, walk, q + 1, tile);
     resid_issue();  // next tile's residual, requested before this tile's epilogue (see gemm_pp256_kernel)
-    pp_epilogue<EPI, 2, 3>(g, acc, lane, done.bz, w_unscale, bias_lds, lds + RING + PP_BIAS_BYTES + wave * 4096,
-                           [&](int mi) { return done.m0 + wm * 64 + mi * 32; }, [&](int ni) { return done.n0 + wn * 32 + ni * 64; }, (dbg & 2) != 0);
-    init_acc();
+    pp_walk_epilogue<EPI, BM, BN, 2, 3>(g, walk, done, acc, lane, wave, w_unscale, bias_lds, lds + RING + PP_BIAS_BYTES + wave * 4096,
+                                        [&](int mi) { return done.m0 + wm * 64 + mi * 32; }, [&](int ni) { return done.n0 + wn * 32 + ni * 64; }, (dbg & 2) != 0);
+    init_acc(w_scale);
     if (grp == 1) PP_BARRIER();
     if (!more) break;
   }
@@ -478,11 +589,55 @@ int pp_num_cus() {
   return n;
 }
 
-int g_pp_mode = [] { const char* e = getenv("CTK_GEMM_PP"); return e ? atoi(e) : 1; }();  // (env: initial value, read once) bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; experiments: bit 1 = no stores, bits 8.. = start stagger
+int g_pp_mode = [] { const char* e = getenv("CTK_GEMM_PP"); return e ? atoi(e) : 1; }();  // (env: initial value, read once) bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; bit 4 (16): stream-K walk where a scratch buffer was lent (OFF by default, see the tile walk); experiments: bit 1 = no stores, bit 3 = timing jitter, bits 8.. = start stagger
+
+thread_local void* t_sk_mem = nullptr;
+thread_local size_t t_sk_bytes = 0;
+thread_local hipStream_t t_sk_stream = nullptr;
 
 }  // namespace
 
+size_t ctk_pp_scratch_bytes() { return (size_t)PP_SK_FLAG_BYTES + (size_t)pp_num_cus() * PP_SK_SLOT_MAX; }
+
+CtkPPScratchScope::CtkPPScratchScope(void* mem, size_t bytes, hipStream_t s) : prev_mem_(t_sk_mem), prev_bytes_(t_sk_bytes), prev_stream_(t_sk_stream) {
+  if (mem && bytes >= ctk_pp_scratch_bytes() && (g_pp_mode & 16) != 0 && hipMemsetAsync(mem, 0, PP_SK_FLAG_BYTES, s) == hipSuccess) {
+    t_sk_mem = mem;
+    t_sk_bytes = bytes;
+    t_sk_stream = s;
+  } else {
+    t_sk_mem = nullptr;
+  }
+}
+CtkPPScratchScope::~CtkPPScratchScope() {
+  t_sk_mem = prev_mem_;
+  t_sk_bytes = prev_bytes_;
+  t_sk_stream = prev_stream_;
+}
+
 extern "C" void ctk_gemm_pp_mode(int mode) { g_pp_mode = mode; }
+
+extern "C" int ctk_gemm_scratch_bytes(size_t* out_bytes) {
+  if (!out_bytes) return CTK_E_NULL;
+  *out_bytes = ctk_pp_scratch_bytes();
+  return CTK_OK;
+}
+
+// Lend (or, with mem == null, take back) a stream-K scratch buffer to the ctk_gemm calls this thread issues on `stream`.
+extern "C" int ctk_gemm_set_scratch(void* mem, size_t bytes, void* stream) {
+  t_sk_mem = nullptr;
+  t_sk_bytes = 0;
+  t_sk_stream = nullptr;
+  if (!mem) return CTK_OK;
+  if (!ctk_aligned16(mem)) return CTK_E_ALIGN;
+  if (bytes < ctk_pp_scratch_bytes()) return CTK_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const hipError_t e = hipMemsetAsync(mem, 0, PP_SK_FLAG_BYTES, s);
+  if (e != hipSuccess) return (int)e;
+  t_sk_mem = mem;
+  t_sk_bytes = bytes;
+  t_sk_stream = s;
+  return CTK_OK;
+}
 
 // Returns CTK_OK after launching, or -1 when the shape is not one of the persistent kernels' (caller falls back).
 int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
@@ -502,7 +657,9 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), blk(512);
   const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
   if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
-  const bool dbgk = (g_pp_mode & ~1) != 0;
+  // stream-K only on the stream whose entry point lent the scratch (one persistent GEMM at a time uses the slots)
+  g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;
+  const bool dbgk = (g_pp_mode & ~17) != 0;
 #define PP_CASE(E)                                                                                             \
   case E:                                                                                                      \
     if (t256 && dbgk) hipLaunchKernelGGL((gemm_pp256_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);   \

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 6
+#define CTK_ABI_VERSION 7
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -335,6 +335,14 @@ typedef struct ctk_gemm_args {
   int32_t c_split;         /* write C in SH format: ldc / c_bs count halves, ldc % 64 == 0, no resid; needs Wp */
 } ctk_gemm_args;
 int ctk_gemm(const ctk_gemm_args* g, void* stream);
+/* Stream-K scratch of the persistent split-half kernels (csrc/gemm_pp.hip).  With N = 384 and M = 102400 a Linear of the
+ * path is 800 tiles on 256 CUs -- four rounds, the last 1/8 full -- unless the tiles' K ranges are dealt as one stream; the
+ * two workgroups that then share a tile exchange one partial tile through this buffer (flags + one 256 KiB slot per CU).
+ * ctk_forward_window / ctk_update_former[_ex] carve it from their own workspace; a bare ctk_gemm uses it only after
+ * ctk_gemm_set_scratch(mem, bytes, stream) on the calling thread (mem = NULL takes it back).  Results with and without it
+ * differ in the last bits (the K sum is split at a fixed, shape-dependent place: still deterministic). */
+int ctk_gemm_scratch_bytes(size_t* out_bytes);
+int ctk_gemm_set_scratch(void* mem, size_t bytes, void* stream);
 /* Split a torch-layout weight [N,K] (K % 32 == 0, row stride ldw) into the packed two-half form
  * the split-half back end reads: 64-byte header {s, 1/s} (s = power of two, chosen on the device
  * from max|W|) + [N][K/32][2][32] IEEE halves (hi, lo of s*W).  Done once per weight at load.   */

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SYMBOLS), f"binding/header mismatch: {declared ^ set(_lib.SYMBOLS)}"
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_argument_validation_without_gpu(lib):

@@ -83,3 +83,56 @@ def test_gemm_pp_matches_fp64_old_kernels_and_survives_timing_jitter(case):
         assert torch.equal(_run(case, 1, data), new), "persistent kernel is not deterministic"
     for _ in range(3):
         assert torch.equal(_run(case, 9, data), new), "result depends on wave timing: LDS-DMA / barrier protocol race"
+
+
+# Stream-K walk (ctk_gemm_pp_mode bit 4 + a lent scratch buffer, include/ctk.h: ctk_gemm_set_scratch): OFF by default --
+# measured gain 5 % on mlp.fc2 only, see gemm_pp.hip -- but it must stay correct: the two workgroups sharing a tile exchange
+# a partial tile through cache-bypassing stores / loads and per-wave flags.
+SK_CASES = ["to_q", "to_out", "mlp.fc2", "to_kv"]  # the linear f32 epilogues (the only ones that take part)
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_gemm_pp_stream_k_matches_rounds_is_deterministic_and_survives_jitter(case):
+    import ctypes as C
+
+    from cotracker_amd import _lib, ops
+    M, K, N, act, res, split, brows, bias = CASES[case]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(7 * K + N)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    r = (3 * torch.randn(M, N, generator=g)).to(dev) if res else None
+    data = (ops.split_rows(a), w, ops.pack_weight(w), b, None, r)
+    ref = a.double() @ w.double().t() + b.double()
+    if res:
+        ref += r.double()
+    lib = _lib.load()
+    nbytes = C.c_size_t(0)
+    _lib.check(lib.ctk_gemm_scratch_bytes(C.byref(nbytes)), "ctk_gemm_scratch_bytes")
+    scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    scratch.fill_(0xFF)  # stale partial tiles and garbage behind the flags must not matter
+    stream = torch.cuda.current_stream().cuda_stream
+    rounds = _run(case, 1, data)
+    try:
+        assert lib.ctk_gemm_set_scratch(None, 0, None) == 0
+        assert lib.ctk_gemm_set_scratch(C.c_void_p(scratch.data_ptr() + 4), nbytes.value, C.c_void_p(stream)) == -3  # CTK_E_ALIGN
+        assert lib.ctk_gemm_set_scratch(C.c_void_p(scratch.data_ptr()), nbytes.value - 1, C.c_void_p(stream)) == -4  # CTK_E_WORKSPACE
+        _lib.check(lib.ctk_gemm_set_scratch(C.c_void_p(scratch.data_ptr()), nbytes.value, C.c_void_p(stream)), "ctk_gemm_set_scratch")
+        sk = _run(case, 17, data)
+        tol = 4e-5 * max(1.0, float(ref.abs().max()) / 4)
+        assert float((sk.double() - ref).abs().max()) < tol
+        # the K sum of a shared tile is split at a fixed place: last-bit differences against the round walk, and some must
+        # exist (otherwise the walk was not taken: the shapes above have tiles % 256 != 0)
+        d = float((sk - rounds).abs().max())
+        assert 0.0 < d < tol
+        for _ in range(3):
+            assert torch.equal(_run(case, 17, data), sk), "stream-K walk is not deterministic"
+        for _ in range(3):
+            assert torch.equal(_run(case, 25, data), sk), "stream-K result depends on wave timing"
+        assert torch.equal(_run(case, 1, data), rounds)  # bit 4 clear: the scratch is ignored
+    finally:
+        lib.ctk_gemm_set_scratch(None, 0, None)
+        lib.ctk_gemm_pp_mode(1)
+    flags = scratch[:16384].view(torch.int32)
+    assert int(flags.abs().max()) == 0, "a flag was left raised"

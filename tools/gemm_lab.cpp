@@ -57,7 +57,7 @@ static double gelu_tanh(double x) { return 0.5 * x * (1.0 + std::tanh(0.79788456
 int main(int argc, char** argv) {
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   // "exp m1 m2 ...": timing only, one column per ctk_gemm_pp_mode value (bit 0 = new kernels, bit 1 = no stores, bits 8.. = start stagger)
-  const bool exp_mode = argc > 1 && !strcmp(argv[1], "exp");
+  const bool exp_mode = argc > 1 && (!strcmp(argv[1], "exp") || !strcmp(argv[1], "quant"));
   std::vector<int> exp_modes;
   for (int i = 2; exp_mode && i < argc; ++i) exp_modes.push_back(atoi(argv[i]));
   const int reps = quick ? 3 : 12;
@@ -65,6 +65,13 @@ int main(int argc, char** argv) {
   hipStream_t st;
   HIP_OK(hipStreamCreate(&st));
   printf("ctk abi %d\n", ctk_abi_version());
+  // stream-K scratch for the persistent kernels (used by the modes with bit 4 = 16 set); LAB_OLD = the mode of the "old" column
+  const int old_mode = getenv("LAB_OLD") ? atoi(getenv("LAB_OLD")) : 0;
+  size_t sk_bytes = 0;
+  CTK_OKAY(ctk_gemm_scratch_bytes(&sk_bytes));
+  void* sk_mem = nullptr;
+  HIP_OK(hipMalloc(&sk_mem, sk_bytes));
+  if (!getenv("LAB_NO_SK")) CTK_OKAY(ctk_gemm_set_scratch(sk_mem, sk_bytes, st));
 
   const bool dense = argc > 1 && (!strcmp(argv[1], "dense") || !strcmp(argv[1], "stress"));  // the shapes of tests/test_sharding.py's dense-mode run (S = 8, 3840 points)
   std::vector<Shape> shapes;
@@ -87,6 +94,13 @@ int main(int argc, char** argv) {
   shapes.push_back({"corr_mlp.fc2  ", RP, 384, 256, CTK_ACT_NONE, false, true, false, true, 4});
   shapes.push_back({"corr_mlp.fc1  ", quick ? RP : 4 * RP, 2432, 384, CTK_ACT_GELU_ERF, false, true, false, true, 1});
   }
+  if (argc > 1 && !strcmp(argv[1], "quant")) {  // round quantisation: 768 / 800 / 1024 tiles of 256 x 192 on 256 CUs
+    shapes.clear();
+    for (long m : {98304l, 102400l, 131072l}) {
+      shapes.push_back({"fc2  quant    ", m, 1536, 384, CTK_ACT_NONE, true, false, false, true, 1});
+      shapes.push_back({"to_q quant    ", m, 384, 384, CTK_ACT_NONE, false, false, false, true, 1});
+    }
+  }
   if (argc > 1 && !strcmp(argv[1], "small")) {  // the virtual-track Linears (64 x S rows): 64 x 64 tile kernels
     shapes.clear();
     shapes.push_back({"v.q/out       ", 1024, 384, 384, CTK_ACT_NONE, true, false, false, true, 1});
@@ -95,7 +109,7 @@ int main(int argc, char** argv) {
     shapes.push_back({"v.fc2         ", 1024, 1536, 384, CTK_ACT_NONE, true, false, false, true, 1});
     shapes.push_back({"v.q S=120     ", 7680, 384, 384, CTK_ACT_NONE, true, false, false, true, 1});
   }
-  if (!quick && !dense && !(argc > 1 && !strcmp(argv[1], "small"))) {
+  if (!quick && !dense && !(argc > 1 && (!strcmp(argv[1], "small") || !strcmp(argv[1], "quant")))) {
     // C2 (offline S = 48, N = 400) and C4 (S = 16, N = 1024) token counts: few tiles per CU
     shapes.push_back({"fc1   @C2     ", 22272, 384, 1536, CTK_ACT_GELU_TANH, false, true, false, true, 1});
     shapes.push_back({"to_out@C2     ", 22272, 384, 384, CTK_ACT_NONE, true, false, false, true, 1});
@@ -241,7 +255,7 @@ int main(int argc, char** argv) {
       if (dbr) HIP_OK(hipFree(dbr));
       continue;
     }
-    run(dC0, 0);
+    run(dC0, old_mode);
     run(dC1, 1);
     HIP_OK(hipStreamSynchronize(st));
     std::vector<float> c0((size_t)c_elems), c1((size_t)c_elems), c2((size_t)c_elems);
@@ -302,7 +316,7 @@ int main(int argc, char** argv) {
     // timing, interleaved old / new / old / new
     double t_old = 1e30, t_new = 1e30;
     for (int r = 0; r < 2; ++r) {
-      t_old = std::min(t_old, (double)time_mode(dC0, 0));
+      t_old = std::min(t_old, (double)time_mode(dC0, old_mode));
       t_new = std::min(t_new, (double)time_mode(dC1, 1));
     }
     const double flops = 2.0 * M * N * (double)K * B;
