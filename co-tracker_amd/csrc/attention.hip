@@ -188,16 +188,69 @@ constexpr int VP = 72;              // V^T image row pitch in halves: 9 slots
 constexpr float PSCALE = 4096.0f;
 constexpr int QT_PER_WG = 4;        // 128-query tiles per workgroup of attention_kv64_kernel
 
+// ---- SH output of one head of a 32-query tile: whole lines instead of 16-byte crumbs ---------------------------
+// The accumulator layout hands a lane (query r32, half) 4 consecutive output columns per register quad; written from
+// there a store instruction touches 32 rows x 16 bytes, and a CU retires such an instruction only every ~100 cycles
+// (tools/gemm_lab.cpp store experiments): 12 of them per 32-query job were half of attention_p2v's and a third of
+// attention_time's launch time.  A head's 48 columns are one whole 128-byte SH line (32 hi | 32 lo halves) plus half of
+// a line it shares with its neighbour head (16 hi halves = 32 bytes, 16 lo halves = 32 bytes).  The job's output goes
+// through a wave-private LDS image -- [32 rows][full line 128 B | hi part 32 B | lo part 32 B], pitch 208 B -- and
+// leaves as 6 instructions whose lanes (row, 16-byte chunk) cover a row's 192 bytes in order.  Same values, same bits.
+constexpr int OIMG_PITCH = 208;
+constexpr int OIMG_BYTES = 32 * OIMG_PITCH;  // 6656 per wave
+
+// d0 = first of 4 consecutive head dims (multiple of 4) -> byte position of their hi halves in the row image (lo: +64 in
+// the full line, +32 in the part)
+__device__ __forceinline__ int oimg_pos(const bool odd_head, const int d0) {
+  if (!odd_head) return d0 < 32 ? d0 * 2 : 128 + (d0 - 32) * 2;
+  return d0 < 16 ? 128 + d0 * 2 : (d0 - 16) * 2;
+}
+
+// RowPtr: int row (0..31) -> _Float16* start of that query's SH output row, or nullptr when the slot is padding
+template <class RowPtr>
+__device__ __forceinline__ void attn_store_sh_head(const f32x16 (&oacc)[2], const float inv, unsigned char* img /* this wave's */,
+                                                   const int lane, const int head, RowPtr row_ptr) {
+  const int r32 = lane & 31, half = lane >> 5;
+  const bool odd = head & 1;
+  unsigned char* wr = img + r32 * OIMG_PITCH;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (dt == 1 && q >= 2) continue;  // dims 48..63 do not exist
+      const int d0 = dt * 32 + q * 8 + half * 4;
+      const f32x4 t = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
+      f16x4 hi, lo;
+      ctk_split4(t, hi, lo);
+      const int pos = oimg_pos(odd, d0);
+      *reinterpret_cast<f16x4*>(wr + pos) = hi;
+      *reinterpret_cast<f16x4*>(wr + pos + (pos < 128 ? 64 : 32)) = lo;
+    }
+  // global byte offsets inside the row: the head's whole line, and the shared line's half
+  const int line_full = odd ? (3 * head + 1) / 2 : (3 * head) / 2;       // (48 head + 16) / 32  |  48 head / 32
+  const int line_part = odd ? (3 * head) / 2 : (3 * head) / 2 + 1;
+  const int part_off = odd ? 32 : 0;                                       // odd heads own columns 16..31 of the shared line
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int idx = k * 64 + lane, row = idx / 12, c = idx - row * 12;
+    const f16x8 v = *reinterpret_cast<const f16x8*>(img + row * OIMG_PITCH + c * 16);
+    _Float16* base = row_ptr(row);
+    const int off = c < 8 ? line_full * 128 + c * 16 : line_part * 128 + part_off + (c < 10 ? (c - 8) * 16 : 64 + (c - 10) * 16);
+    if (base) *reinterpret_cast<f16x8*>(reinterpret_cast<unsigned char*>(base) + off) = v;
+  }
+}
+
 // ---- n2 == 64 keys (points <- virtual, virtual self): workgroup = (frame b, head, QT_PER_WG x 128 queries) ----
 // K [64][48] and V^T [48][64 keys, permuted] of this (b, head) are split once into LDS; every wave then takes 32
 // queries at a time: Q fragment from global (scaled, split in registers), 18 MFMAs for S', in-register softmax,
 // 24 MFMAs for O^T, float4 / SH stores (a lane owns 4 consecutive output columns per register quad).
 __global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * 64 * KP + 2 * 64 * VP];
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * 64 * KP + 2 * 64 * VP + 4 * OIMG_BYTES / 2];
   _Float16* kimg = lds;                 // [hi|lo][64 keys][KP]
   _Float16* vimg = lds + 2 * 64 * KP;   // [hi|lo][64 dims (48 used)][VP]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r32 = lane & 31, half = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
+  unsigned char* oimg = reinterpret_cast<unsigned char*>(lds + 2 * 64 * KP + 2 * 64 * VP) + wave * OIMG_BYTES;  // SH output image of this wave
 
   for (int i = tid; i < 64 * (HD / 4); i += 256) {
     const int key = i / (HD / 4), d4 = i - key * (HD / 4);
@@ -303,8 +356,13 @@ __global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
         oacc[dt] = ctk_mma3(vh, vl, ph, pl, oacc[dt]);
       }
     }
-    if (q0 + r32 < p.n1) {
-      const float inv = 1.0f / (sum * PSCALE);
+    const float inv = 1.0f / (sum * PSCALE);
+    if (p.o_split) {
+      attn_store_sh_head(oacc, inv, oimg, lane, head, [&](int row) -> _Float16* {
+        const int qr = q0 + row;
+        return qr < p.n1 ? reinterpret_cast<_Float16*>(p.out) + ((long)b * p.o_bs + (long)qr * p.o_is) * p.o_ld : nullptr;
+      });
+    } else if (q0 + r32 < p.n1) {
       const long orow = ((long)b * p.o_bs + (long)qi * p.o_is) * p.o_ld;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -313,15 +371,7 @@ __global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
           const int d = dt * 32 + q * 8 + half * 4;
           if (d < HD) {
             const f32x4 t = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
-            if (p.o_split) {
-              f16x4 hi, lo;
-              ctk_split4(t, hi, lo);
-              _Float16* dst = reinterpret_cast<_Float16*>(p.out) + orow + ctk_sh_col(head * HD + d);
-              *reinterpret_cast<f16x4*>(dst) = hi;
-              *reinterpret_cast<f16x4*>(dst + 32) = lo;
-            } else {
-              *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
-            }
+            *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
           }
         }
     }
@@ -543,7 +593,9 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
 // with online softmax.  K and V^T fragments come straight from global memory as in attention_q64_kernel.
 template <int PACK>  // batches per score tile: 2 when n1 <= 16, else 1
 __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) unsigned char oimg_all[4 * OIMG_BYTES];  // SH output images (attn_store_sh_head), one per wave
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r32 = lane & 31, half = lane >> 5;
+  unsigned char* oimg = oimg_all + wave * OIMG_BYTES;
   const int head = blockIdx.y;
   constexpr int pack = PACK;
   constexpr int spb = 32 / pack;     // tile slots per batch
@@ -640,8 +692,13 @@ __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
     }
   }
   l += __shfl_xor(l, 32, 64);
-  if (qvalid) {
-    const float inv = 1.0f / (l * PSCALE);
+  const float inv = 1.0f / (l * PSCALE);
+  if (p.o_split) {
+    attn_store_sh_head(oacc, inv, oimg, lane, head, [&](int row) -> _Float16* {
+      const int ob = b0 + row / spb, oi = qtile * spb + row % spb;
+      return (ob < p.nbatch && oi < p.n1) ? reinterpret_cast<_Float16*>(p.out) + ((long)ob * p.o_bs + (long)oi * p.o_is) * p.o_ld : nullptr;
+    });
+  } else if (qvalid) {
     const long orow = ((long)qbc * p.o_bs + (long)qic * p.o_is) * p.o_ld;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -650,15 +707,7 @@ __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
         const int d = dt * 32 + q * 8 + half * 4;
         if (d < HD) {
           const f32x4 t = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
-          if (p.o_split) {
-            f16x4 hi, lo;
-            ctk_split4(t, hi, lo);
-            _Float16* dst = reinterpret_cast<_Float16*>(p.out) + orow + ctk_sh_col(head * HD + d);
-            *reinterpret_cast<f16x4*>(dst) = hi;
-            *reinterpret_cast<f16x4*>(dst + 32) = lo;
-          } else {
-            *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
-          }
+          *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
         }
       }
   }
@@ -677,7 +726,9 @@ struct TimeRaw {
 };
 
 __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long njobs) {
+  __shared__ __attribute__((aligned(16))) unsigned char oimg_all[4 * OIMG_BYTES];  // SH output images (attn_store_sh_head), one per wave
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r32 = lane & 31, half = lane >> 5;
+  unsigned char* oimg = oimg_all + wave * OIMG_BYTES;
   const long stride = (long)gridDim.x * 4;
   long job = (long)blockIdx.x * 4 + wave;
   if (job >= njobs) return;  // wave-uniform
@@ -769,8 +820,13 @@ __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long 
       oacc[1] = ctk_mma3(vh[1][s], vl[1][s], ph, pl, oacc[1]);
     }
     l += __shfl_xor(l, 32, 64);
-    if (qvalid) {
-      const float inv = 1.0f / (l * PSCALE);
+    const float inv = 1.0f / (l * PSCALE);
+    if (p.o_split) {
+      attn_store_sh_head(oacc, inv, oimg, lane, head, [&](int row) -> _Float16* {
+        const int ob = b0 + (row >> 4), oi = row & 15;
+        return (ob < p.nbatch && oi < p.n1) ? reinterpret_cast<_Float16*>(p.out) + ((long)ob * p.o_bs + (long)oi * p.o_is) * p.o_ld : nullptr;
+      });
+    } else if (qvalid) {
       const long orow = ((long)(b0 + rb) * p.o_bs + (long)ri * p.o_is) * p.o_ld;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -779,15 +835,7 @@ __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long 
           const int d = dt * 32 + q * 8 + half * 4;
           if (d < HD) {
             const f32x4 t = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
-            if (p.o_split) {
-              f16x4 hi, lo;
-              ctk_split4(t, hi, lo);
-              _Float16* dst = reinterpret_cast<_Float16*>(p.out) + orow + ctk_sh_col(head * HD + d);
-              *reinterpret_cast<f16x4*>(dst) = hi;
-              *reinterpret_cast<f16x4*>(dst + 32) = lo;
-            } else {
-              *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
-            }
+            *reinterpret_cast<f32x4*>(p.out + orow + head * HD + d) = t;
           }
         }
     }
