@@ -21,6 +21,17 @@ except Exception as e:
     except Exception: pass
 PY
 }
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    cd /tmp && rm -rf /tmp/pmc_$c && rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /tmp/pmc_$c.log 2>&1
+    cd $GRAFT_REPO_ROOT
+  done
+  ff=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py "$ff" "$fw" gpurun_out/r03_pmc_traffic.json c3_sliding > gpurun_out/r03_pmc_traffic.txt 2>&1
+  head -30 gpurun_out/r03_pmc_traffic.txt
+  cp gpurun_out/r03_pmc_traffic.json profiles/pmc_traffic.json  # (on the box: the bench lines below attach it; its library hash is this build's)
+fi
+
 if has lab; then
   (timeout 600 tools/gemm_lab 2>&1 | tail -20) | tee gpurun_out/r03_gemm_lab.log
 fi
@@ -57,13 +68,4 @@ if has sq; then
   cd $GRAFT_REPO_ROOT
   python tools/summarize_counters.py /tmp/sq gpurun_out/r03_sq_counters.txt | head -24
   python tools/summarize_counters.py /tmp/ldsc gpurun_out/r03_lds_counters.txt | head -14
-fi
-if has pmc; then
-  for c in FETCH_SIZE WRITE_SIZE; do
-    cd /tmp && rm -rf /tmp/pmc_$c && rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /tmp/pmc_$c.log 2>&1
-    cd $GRAFT_REPO_ROOT
-  done
-  ff=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-  python tools/pmc_traffic.py "$ff" "$fw" gpurun_out/r03_pmc_traffic.json c3_sliding > gpurun_out/r03_pmc_traffic.txt 2>&1
-  head -30 gpurun_out/r03_pmc_traffic.txt
 fi
