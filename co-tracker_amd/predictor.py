@@ -159,6 +159,14 @@ class CoTrackerOnlinePredictor(torch.nn.Module):
         self.model.eval()
         self.model.hip_graph = True  # streaming: replay the captured window graph per chunk (configs[3])
 
+    def finish(self):
+        """Not in the reference (its stream has no end marker): examine the f16-range check of the LAST chunk, which graph
+        streaming defers to the next call (behaviours table).  Raises FloatingPointError like that next call
+        would; a no-op for CoTracker2 (unguarded) and when nothing is pending."""
+        resolve = getattr(self.model, "_resolve_deferred_range_check", None)
+        if resolve is not None:
+            resolve()
+
     @torch.no_grad()
     def forward(self, video_chunk, is_first_step: bool = False, queries: torch.Tensor = None, grid_size: int = 5,
                 grid_query_frame: int = 0, add_support_grid=False):
