@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
   printf("ctk abi %d\n", ctk_abi_version());
   // stream-K scratch for the persistent kernels (used by the modes with bit 4 = 16 set); LAB_OLD = the mode of the "old" column
   const int old_mode = getenv("LAB_OLD") ? atoi(getenv("LAB_OLD")) : 0;
+  const int new_mode = getenv("LAB_NEW") ? atoi(getenv("LAB_NEW")) : 1;
   size_t sk_bytes = 0;
   CTK_OKAY(ctk_gemm_scratch_bytes(&sk_bytes));
   void* sk_mem = nullptr;
@@ -256,7 +257,7 @@ int main(int argc, char** argv) {
       continue;
     }
     run(dC0, old_mode);
-    run(dC1, 1);
+    run(dC1, new_mode);
     HIP_OK(hipStreamSynchronize(st));
     std::vector<float> c0((size_t)c_elems), c1((size_t)c_elems), c2((size_t)c_elems);
     HIP_OK(hipMemcpy(c0.data(), dC0, c_elems * 4, hipMemcpyDeviceToHost));
@@ -264,7 +265,7 @@ int main(int argc, char** argv) {
     // determinism of the new kernel
     int nondet = 0;
     for (int r = 0; r < (quick ? 2 : 4); ++r) {
-      run(dC2, 1);
+      run(dC2, new_mode);
       HIP_OK(hipStreamSynchronize(st));
       HIP_OK(hipMemcpy(c2.data(), dC2, c_elems * 4, hipMemcpyDeviceToHost));
       if (memcmp(c1.data(), c2.data(), c_elems * 4)) ++nondet;
@@ -317,7 +318,7 @@ int main(int argc, char** argv) {
     double t_old = 1e30, t_new = 1e30;
     for (int r = 0; r < 2; ++r) {
       t_old = std::min(t_old, (double)time_mode(dC0, old_mode));
-      t_new = std::min(t_new, (double)time_mode(dC1, 1));
+      t_new = std::min(t_new, (double)time_mode(dC1, new_mode));
     }
     const double flops = 2.0 * M * N * (double)K * B;
     printf("%s M=%7ld K=%4d N=%4d B=%d | old %8.1f us %6.1f TF (%.3f) | new %8.1f us %6.1f TF (%.3f) | x%.2f | err vs fp64 old %.2e new %.2e (tol %.1e) old-new %.2e nondet %d %s\n",
