@@ -182,6 +182,12 @@ def test_overflow_gives_defined_result_not_nan():
     m(video[:, 0:8], q, iters=2, is_online=True)
     with pytest.raises(FloatingPointError, match="f16 range"):
         m(video[:, 4:12], q, iters=2, is_online=True)
+    # ... and when no next call comes (the LAST chunk of a stream), CoTrackerOnlinePredictor.finish() examines it: same error
+    m.init_video_online_processing()
+    m(video[:, 0:8], q, iters=2, is_online=True)
+    with pytest.raises(FloatingPointError, match="f16 range"):
+        m._resolve_deferred_range_check()  # = what predictor.finish() calls
+    m._resolve_deferred_range_check()      # nothing pending any more: a no-op
     m.hip_graph = False
     # streaming without the graph: immediate check, the online state is restored before the f32 re-run
     m.init_video_online_processing()
