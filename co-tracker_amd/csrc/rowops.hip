@@ -46,11 +46,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y
     f32x4 o = v[k] * rstd;
     if (gamma) o = o * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
     if (out_split) {
+      // Whole lines: lanes j and j ^ 1 hold 8 consecutive columns; the even lane stores their 8 hi halves (own quad + the
+      // neighbour's), the odd lane their 8 lo halves -- 16 bytes each, and the 32 lanes of a row cover 512 consecutive bytes
+      // (4 SH lines) per instruction instead of eight 64-byte half-lines in two instructions (round 3, same bits).
       f16x4 hi, lo;
       ctk_split4(o, hi, lo);
-      _Float16* dst = yh + ctk_sh_col(c);
-      *reinterpret_cast<f16x4*>(dst) = hi;
-      *reinterpret_cast<f16x4*>(dst + 32) = lo;
+      const bool odd = j & 1;
+      const f32x2 give = __builtin_bit_cast(f32x2, odd ? hi : lo);
+      const f32x2 got = {__shfl_xor(give[0], 1, 64), __shfl_xor(give[1], 1, 64)};
+      const f16x4 theirs = __builtin_bit_cast(f16x4, got);
+      const f16x8 piece = odd ? ctk_cat8(theirs, lo) : ctk_cat8(hi, theirs);
+      _Float16* dst = yh + ctk_sh_col(c & ~7) + (odd ? 32 : 0);
+      *reinterpret_cast<f16x8*>(dst) = piece;
     } else {
       *reinterpret_cast<f32x4*>(yr + 128 * k) = o;
     }
@@ -60,52 +67,57 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y
 // ---- token assembly: x[n*S+t][1024..1119] = [vis, conf, posenc(rel fwd/bwd coords), 0-pad] ---
 // cotracker3_online.py:212-245 and posenc :19-39.  The time embedding (:247) is folded into the
 // input projection's per-frame bias (ctk_model_weights.in_bias_t).
+// One thread = 8 consecutive columns of a row (12 threads per row): a 16-byte hi piece and a 16-byte lo piece per thread.  Round 2
+// wrote every element with two 2-byte stores, and at ~100 cycles per store instruction and CU (tools/gemm_lab.cpp) the 300 k store
+// instructions of a launch were its whole 54 us; same values, same bits.
+__device__ __forceinline__ float assemble_value(const float* coords, const float* vis, const float* conf, int S, int N, float scale_x,
+                                                float scale_y, int t, int n, int e) {
+  if (e == 0) return vis[(long)t * N + n];
+  if (e == 1) return conf[(long)t * N + n];
+  if (e >= 2 + 84) return 0.0f;
+  const int k = e - 2;  // posenc element 0..83
+  int comp, deg;
+  bool shift = false;
+  if (k < 4) { comp = k; deg = -1; }
+  else if (k < 44) { comp = (k - 4) & 3; deg = (k - 4) >> 2; }
+  else { comp = (k - 44) & 3; deg = (k - 44) >> 2; shift = true; }
+  // comp 0,1 = forward (c[t]-c[t+1]) x,y ; comp 2,3 = backward (c[t]-c[t-1]) x,y
+  const int axis = comp & 1;
+  const bool fwd = comp < 2;
+  const int tn = fwd ? t + 1 : t - 1;
+  float rel = 0.0f;
+  if (tn >= 0 && tn < S) rel = __fsub_rn(coords[((long)t * N + n) * 2 + axis], coords[((long)tn * N + n) * 2 + axis]);
+  rel = __fdiv_rn(rel, axis == 0 ? scale_x : scale_y);
+  if (deg < 0) return rel;
+  float a = __fmul_rn(rel, (float)(1 << deg));
+  if (shift) a = __fadd_rn(a, 1.57079637050628662109375f);  // f32(0.5*pi)
+  return sinf(a);
+}
+
 __global__ void assemble_kernel(const float* coords, const float* vis, const float* conf, int S, int N, float scale_x,
                                 float scale_y, float* x, int x_split) {
   constexpr int EW = CTK_X_LD - CTK_X_VIS;  // 96 columns written per row
+  constexpr int G8 = EW / 8;                // 12 column octets
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)S * N * EW;
+  const long total = (long)S * N * G8;
   if (i >= total) return;
-  const int e = i % EW;
-  const long row = i / EW;  // n*S + t
+  const int e0 = (int)(i % G8) * 8;
+  const long row = i / G8;  // n*S + t
   const int t = row % S;
   const int n = row / S;
-  float out;
-  if (e == 0) {
-    out = vis[(long)t * N + n];
-  } else if (e == 1) {
-    out = conf[(long)t * N + n];
-  } else if (e >= 2 + 84) {
-    out = 0.0f;
-  } else {
-    const int k = e - 2;  // posenc element 0..83
-    int comp, deg;
-    bool shift = false;
-    if (k < 4) { comp = k; deg = -1; }
-    else if (k < 44) { comp = (k - 4) & 3; deg = (k - 4) >> 2; }
-    else { comp = (k - 44) & 3; deg = (k - 44) >> 2; shift = true; }
-    // comp 0,1 = forward (c[t]-c[t+1]) x,y ; comp 2,3 = backward (c[t]-c[t-1]) x,y
-    const int axis = comp & 1;
-    const bool fwd = comp < 2;
-    const int tn = fwd ? t + 1 : t - 1;
-    float rel = 0.0f;
-    if (tn >= 0 && tn < S) rel = __fsub_rn(coords[((long)t * N + n) * 2 + axis], coords[((long)tn * N + n) * 2 + axis]);
-    rel = __fdiv_rn(rel, axis == 0 ? scale_x : scale_y);
-    if (deg < 0) {
-      out = rel;
-    } else {
-      float a = __fmul_rn(rel, (float)(1 << deg));
-      if (shift) a = __fadd_rn(a, 1.57079637050628662109375f);  // f32(0.5*pi)
-      out = sinf(a);
-    }
-  }
+  f32x4 v[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k >> 2][k & 3] = assemble_value(coords, vis, conf, S, N, scale_x, scale_y, t, n, e0 + k);
   if (x_split) {  // SH row: 35 tiles x 64 halves
-    _Float16* xh = reinterpret_cast<_Float16*>(x) + row * (2 * CTK_X_LD) + ctk_sh_col(CTK_X_VIS + e);
-    const _Float16 hi = (_Float16)out;
-    xh[0] = hi;
-    xh[32] = (_Float16)(out - (float)hi);
+    _Float16* xh = reinterpret_cast<_Float16*>(x) + row * (2 * CTK_X_LD) + ctk_sh_col(CTK_X_VIS + e0);
+    f16x8 hi, lo;
+    ctk_split8(v[0], v[1], hi, lo);
+    *reinterpret_cast<f16x8*>(xh) = hi;
+    *reinterpret_cast<f16x8*>(xh + 32) = lo;
   } else {
-    x[row * CTK_X_LD + CTK_X_VIS + e] = out;
+    float* xp = x + row * CTK_X_LD + CTK_X_VIS + e0;
+    *reinterpret_cast<f32x4*>(xp) = v[0];
+    *reinterpret_cast<f32x4*>(xp + 4) = v[1];
   }
 }
 
@@ -174,8 +186,8 @@ extern "C" int ctk_layernorm(const float* x, void* y, int64_t R, const float* ga
 extern "C" int ctk_assemble_tokens(const ctk_window_args* a, void* x, int32_t x_split, void* stream) {
   if (!a || !a->coords || !a->vis || !a->conf || !x) return CTK_E_NULL;
   if (a->S <= 0 || a->N <= 0 || !(a->scale_x > 0.f) || !(a->scale_y > 0.f)) return CTK_E_SHAPE;
-  const long total = (long)a->S * a->N * (CTK_X_LD - CTK_X_VIS);
-  CtkProfScope ps("assemble_tokens", 0.0, 4.0 * total, static_cast<hipStream_t>(stream));
+  const long total = (long)a->S * a->N * ((CTK_X_LD - CTK_X_VIS) / 8);  // threads: 8 columns each
+  CtkProfScope ps("assemble_tokens", 0.0, 32.0 * total, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a->coords, a->vis, a->conf, a->S, a->N, a->scale_x, a->scale_y,
                      static_cast<float*>(x), x_split);
