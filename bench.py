@@ -12,11 +12,17 @@ metric = tracked-point-frames/s = N*T / seconds per step, summed over ranks (wea
 rank tracks its own 6400-point chunk; results are all-gathered inside the timed region).
 
 Prints ONE JSON line (rank 0) with the contract keys plus
-  roofline     -- dominant kernel (recorder rows are per GEMM shape), algorithmic flops / HIP-event duration vs the
-                  split-half MFMA ceiling; roofline_gemm = all Linear launches call-weighted; roofline_sampler = the
-                  correlation sampler against max(measured HBM bytes / 8 TB/s, flops / MFMA ceiling)
+  roofline     -- the TIME-DOMINANT CLASS of kernels of the step (all Linear GEMM launches call-weighted, or the correlation
+                  sampler): algorithmic flops / HIP-event duration vs the split-half MFMA ceiling (2500/3 TF/s), with
+                  frac_at_sustained_clock = issued f16 MFMA rate / the rate ctk_probe_mfma(kind 2) holds in THIS run
+                  (sustained_mfma: TF/s and the clock it implies); traffic = call-weighted HBM bytes per launch from the committed
+                  rocprofv3 --pmc passes (profiles/pmc_traffic.json, stamped with the library hash; not re-measured here)
+  roofline_gemm / roofline_sampler -- both classes under their own keys; the sampler with frac_measured (max(measured HBM
+                  bytes / 8 TB/s, flops / MFMA ceiling) / launch time) and frac_no_reuse (SURVEY 8d's algorithmic bytes)
+  extra_lines  -- the same protocol on the exact-f32 back end (value_f32), BASELINE configs[1] (C2) and configs[3] (C4, feature
+                  cache off = reference behaviour, and on)
   cpu_baseline -- oracle/torch_port.py (the reference's ATen CPU kernels in the reference's order, encoder included)
-                  timed on this host's cores on a bounded sample of the same workload
+                  timed on this host's cores (CPU model stated) on a bounded sample of the same workload
   parity       -- max-abs error of THIS run's tracks / logits against the unmodified reference's CPU outputs at
                   BASELINE scale (tests/golden/scale_*.npz), next to the reference's own thread-count noise
   kernels      -- per-kernel launch counts / avg duration / achieved rate from the same HIP events
@@ -71,7 +77,10 @@ def parse():
     ap.add_argument("--workload", default="c3_sliding", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extra-lines", action="store_true", help="skip the extra timed rows (exact-f32 back end, C2, C4) of the default run")
     ap.add_argument("--no-graph", action="store_true", help="c4_online: direct launches instead of the captured hipGraph")
+    ap.add_argument("--feature-cache", action="store_true", help="c4_online: opt in to model.online_feature_cache (re-use the previous "
+                    "chunk's features for the overlapping frames; the reference re-encodes them)")
     ap.add_argument("--pmc-traffic", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-kernel HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -84,17 +93,43 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    """The host CPU as /proc/cpuinfo names it (model string, sockets, physical cores, logical CPUs)."""
+    info = {"model": None, "sockets": None, "physical_cores": None, "logical_cpus": os.cpu_count()}
+    try:
+        phys, cores = set(), set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and info["model"] is None:
+                info["model"] = v
+            elif k == "physical id":
+                pid = v
+                phys.add(v)
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                cores.add((pid, cid))
+                pid = cid = None
+        info["sockets"] = len(phys) or None
+        info["physical_cores"] = len(cores) or None
+    except OSError:
+        pass
+    return info
+
+
 def cpu_baseline(workload):
     """oracle/torch_port.py (kind "port-torch": the ATen CPU ops the reference calls, in its order, encoder included)
     in a subprocess with glibc malloc tuned (see torch_port.MALLOC_ENV), on a bounded sample of the workload:
-    same video size / window length / weights, fewer frames and points so that it finishes in ~10-30 s."""
+    same video size / window length / weights, fewer frames and points so that it finishes in ~30-60 s."""
     import subprocess
     from oracle.torch_port import MALLOC_ENV
     H, W, T, G, offline, wl, _ = WORKLOADS[workload]
     if offline is True:
         kind, frames, grid = "offline", min(T, 48), 20
-    else:  # sliding windows (c3 / c4 / c5): 2 windows of 16 frames, 400 points
-        kind, frames, grid = "sliding", 24, 20
+    else:  # sliding windows (c3 / c4 / c5): 3 windows of 16 frames, 1600 points (a quarter of the headline's per-window rows)
+        kind, frames, grid = "sliding", 32, 40
     env = dict(os.environ, **MALLOC_ENV)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     # intra-op threads: ATen's CPU kernels stop scaling well before a 128-core host is full on tensors of this size
@@ -102,19 +137,21 @@ def cpu_baseline(workload):
     threads = min(32, os.cpu_count() or 1)
     cmd = [sys.executable, "-m", "oracle.torch_port", "--bench", kind, "--frames", str(frames), "--grid", str(grid),
            "--size", str(H), "--threads", str(threads)]
+    host = cpu_model()
     try:
         out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
         r = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
-        return {"value": None, "unit": "tracked-point-frames/s", "cores": os.cpu_count(), "kind": "port-torch",
+        return {"value": None, "unit": "tracked-point-frames/s", "cores": os.cpu_count(), "kind": "port-torch", "host_cpu": host,
                 "sample": f"failed: {type(e).__name__}: {e}"}
     res = {"value": r["tracked_point_frames_per_s"], "unit": "tracked-point-frames/s", "cores": r["threads"],
-           "kind": "port-torch", "host_logical_cpus": os.cpu_count(), "seconds": r["seconds"],
-           # the sample is the bench workload's video size / window length / weights at FEWER frames and points (a ~10-30 s CPU
-           # budget); it is NOT the headline configuration and the value is not rescaled to it
-           "sample_is_config": False, "sample_frames": r["frames"], "sample_points": r["points"],
+           "kind": "port-torch", "host_cpu": host, "host_logical_cpus": os.cpu_count(), "seconds": r["seconds"],
+           # the sample is the bench workload's video size / window length / weights at FEWER frames and points (a ~30-60 s CPU
+           # budget); it is NOT the headline configuration and the value is NOT rescaled to it ("rescaled_to_config": false)
+           "sample_is_config": False, "rescaled_to_config": False, "sample_frames": r["frames"], "sample_points": r["points"],
            "sample": f"oracle/torch_port.py predictor path incl. encoder, {kind}, {r['video'][0]}x{r['video'][1]} video, "
-                     f"T={r['frames']}, N={r['points']} (grid {grid}), 6 iterations, {r['threads']} threads, glibc malloc "
+                     f"T={r['frames']}, N={r['points']} (grid {grid}), 6 iterations, {r['threads']} threads of "
+                     f"{host['model']} ({host['sockets']} sockets, {host['physical_cores']} cores, {host['logical_cpus']} logical), glibc malloc "
                      f"tuned ({r['malloc_tuned']}): {r['seconds']} s; value = N*T/s of that sample (not rescaled)"}
     # what the UNMODIFIED reference did in the build container on the BASELINE-scale goldens (recorded by
     # tests/golden/make_golden_scale.py): same metric, different host
@@ -154,23 +191,85 @@ SPLIT_NOTE = ("achieved = algorithmic (f32-equivalent) flops / HIP-event time; e
               "mfma_peak.  The exact-f32 MFMA peak is 157.3 TF/s")
 
 
-def roofline_mfma(name, rows, traffic):
+# Recorder rows whose contraction runs on the EXACT-f32 MFMA (v_mfma_f32_32x32x2_f32: gemm.hip, corr.hip's corr_volume) or on
+# the VALU (corrblock_sample).  EVERY other row with MFMA flops -- the split-half GEMMs (gemm_sh*, gemm_f16x3*), the
+# implicit-GEMM convolutions of the encoder (conv_pp128_*), the split-half sampler, the attention kernels -- issues 3
+# v_mfma_f32_32x32x16_f16 per product and is priced against 2500/3 TF/s.  (Round 3 keyed this on a list of split-half name
+# prefixes, which priced conv_pp128_* against 157 TF/s: frac 0.93 instead of 0.18.)
+EXACT_F32_ROWS = ("gemm_f32", "corrblock_sample")
+
+
+def is_exact_f32(name):
+    return name.startswith(EXACT_F32_ROWS) or name == "corr_volume"
+
+
+def mfma_peak(name):
+    return FP32_MFMA_PEAK_TFLOPS if is_exact_f32(name) else F16_MFMA_PEAK_TFLOPS / 3.0
+
+
+def roofline_mfma(name, rows, traffic, sustained=None):
     """MFMA roofline of one recorder row, or of several rows together (call-weighted: summed flops / summed time).
-    Split-half kernels form every f32-class product from 3 f16 MFMAs -> ceiling 2500/3 = 833 TF/s algorithmic."""
+    Split-half kernels form every f32-class product from 3 f16 MFMAs -> ceiling 2500/3 = 833 TF/s algorithmic.
+    `sustained` (bench.sustained_mfma): the f16 MFMA rate this chip holds under its power cap -> frac_at_sustained_clock."""
     sec = sum(r["total_ms"] for r in rows) * 1e-3
     n = max(sum(r["launches"] for r in rows), 1)
     flops = sum(r["flops"] for r in rows)
     ach = flops / sec / 1e12
-    split = name.startswith(("gemm_sh", "gemm_f16x3", "corr_volume_sh", "corr_fused", "gemm (all"))
+    exact = [is_exact_f32(r["name"]) for r in rows]
+    assert all(exact) or not any(exact), "a call-weighted row set must not mix exact-f32 and split-half kernels"
+    split = not exact[0]
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
     out = {"kernel": name, "launches": n, "avg_launch_us": round(1e6 * sec / n, 1), "bound": "mfma", "achieved": round(ach, 2),
            "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flops_per_launch": flops / n}
     if split:
         out.update({"mfma_issued": round(3 * ach, 1), "mfma_peak": F16_MFMA_PEAK_TFLOPS, "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
                     "note": SPLIT_NOTE})
+        if sustained and sustained.get("f16_tflops"):
+            out["frac_at_sustained_clock"] = round(3 * ach / sustained["f16_tflops"], 4)
+            out["sustained_mfma_clock_ghz"] = sustained["clock_ghz"]
     else:
         out["note"] = "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) peak"
-    return _traffic_fields(out, traffic.get(name) if len(rows) == 1 else None)
+    if len(rows) == 1:
+        return _traffic_fields(out, traffic.get(name))
+    trs = [traffic.get(r["name"]) for r in rows]
+    if all(t and t.get("hbm_bytes_per_launch") for t in trs):  # call-weighted HBM bytes per launch of the class
+        tot = sum(t["hbm_bytes_per_launch"] * r["launches"] for t, r in zip(trs, rows))
+        agg = {"hbm_bytes_per_launch": tot / n, "source": trs[0].get("source"),
+               "fetch_bytes_per_launch": sum(t.get("fetch_bytes_per_launch", 0.0) * r["launches"] for t, r in zip(trs, rows)) / n,
+               "write_bytes_per_launch": sum(t.get("write_bytes_per_launch", 0.0) * r["launches"] for t, r in zip(trs, rows)) / n,
+               "dispatches": sum(t.get("dispatches", 0) for t in trs)}
+        return _traffic_fields(out, agg)
+    return _traffic_fields(out, None)
+
+
+def sustained_mfma(dev, seconds=1.0):
+    """What the f16 MFMA pipe of THIS chip sustains under its power cap: ctk_probe_mfma kind 2 (register-only loop of
+    v_mfma_f32_32x32x16_f16 on pseudo-random operands, 2 workgroups x 4 waves per CU) run for ~`seconds`, timed with HIP events
+    on the launch stream.  clock = rate / (1024 SIMDs x 1024 flop per clock and SIMD); the nominal 2500 TF/s is 2.4 GHz."""
+    import ctypes as C
+    from cotracker_amd import _lib as L
+    lib = L.load()
+    scratch = torch.zeros(16, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(iters):
+        fl = C.c_double(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.ctk_probe_mfma(2, iters, scratch.data_ptr(), C.byref(fl), stream), "ctk_probe_mfma")
+        e1.record()
+        e1.synchronize()
+        return fl.value, e0.elapsed_time(e1) * 1e-3
+
+    fl, t = run(20000)  # calibrate (~15 ms), then one long launch so that the clock has settled at the cap
+    iters = int(min(max(20000 * seconds / max(t, 1e-4), 20000), 4e6))
+    fl, t = run(iters)
+    fl2, t2 = run(max(iters // 4, 20000))  # the rate right after a second of full load (clock already down)
+    tf = fl / t / 1e12
+    return {"f16_tflops": round(tf, 1), "clock_ghz": round(tf * 1e12 / (1024.0 * 1024.0) / 1e9, 3), "seconds": round(t, 3),
+            "f16_tflops_after": round(fl2 / t2 / 1e12, 1), "nominal_f16_tflops": F16_MFMA_PEAK_TFLOPS, "nominal_clock_ghz": 2.4,
+            "note": "ctk_probe_mfma kind 2: register-only v_mfma_f32_32x32x16_f16 loop on pseudo-random operands, all 256 CUs, "
+                    "measured in this run right after the timed steps; frac_at_sustained_clock = issued f16 MFMA rate / this"}
 
 
 def roofline_sampler(row, traffic):
@@ -199,11 +298,53 @@ def roofline_sampler(row, traffic):
                     "peak": HBM_PEAK_GBS if bound == "hbm" else round(peak_tf, 1), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                     "frac": round(t_bound / t_launch, 4), "hbm_GBs_measured": round(hbm / t_launch / 1e9, 1),
                     "hbm_frac": round(hbm / t_launch / 1e9 / HBM_PEAK_GBS, 4), "roofline_bound_us": round(1e6 * t_bound, 1),
-                    "note": "frac = max(measured HBM bytes / 8 TB/s, flops / 833 TF/s) / measured launch time"})
+                    "frac_measured": round(t_bound / t_launch, 4),
+                    "frac_no_reuse": round(row["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "frac = frac_measured = max(measured HBM bytes / 8 TB/s, flops / 833 TF/s) / measured launch time; "
+                            "frac_no_reuse = SURVEY 8(d)'s algorithmic bytes (every (t,n,level) unit re-reads its own footprint) / 8 TB/s / "
+                            "launch time -- NOT credit: neighbouring points share footprint pixels in L2 / Infinity Cache"})
     else:  # no PMC pass for this kernel on this workload: only the MFMA side is known
         out.update({"bound": "mfma", "achieved": out["mfma_TFLOPs"], "peak": round(peak_tf, 1), "unit": "TFLOP/s",
                     "frac": out["mfma_frac"], "note": "no PMC traffic for this kernel/workload: MFMA side only; HBM traffic unmeasured"})
     return _traffic_fields(out, tr)
+
+
+GEMM_ROW_PREFIXES = ("gemm_sh", "gemm_f16x3", "gemm_f32", "mlp_sh")
+
+
+def rooflines(rows, traffic, sustained=None):
+    """The roofline objects of one profiled step.  `roofline` is the TIME-DOMINANT CLASS of kernels, not the largest single
+    recorder row (rows are per GEMM shape, so the one sampler row used to out-rank 839 ms of GEMM launches): the Linear
+    GEMMs call-weighted, or the correlation sampler, whichever owns more of the step.  Both are always present under their
+    own keys (`roofline_gemm`, `roofline_sampler`)."""
+    out = {}
+    gemm_rows = [r for r in rows if r["name"].startswith(GEMM_ROW_PREFIXES) and r["total_ms"] > 0]
+    samp_rows = [r for r in rows if r["name"].startswith("corr_") and r["total_ms"] > 0]
+    if gemm_rows:
+        exact = is_exact_f32(gemm_rows[0]["name"])
+        same = [r for r in gemm_rows if is_exact_f32(r["name"]) == exact]  # (one back end per run; be safe)
+        g = roofline_mfma("gemm (all Linear launches, call-weighted)", same, traffic, sustained)
+        g["total_ms"] = round(sum(r["total_ms"] for r in same), 2)
+        g["rows"] = [{"name": r["name"], "launches": r["launches"], "avg_us": round(1e3 * r["total_ms"] / max(r["launches"], 1), 1),
+                      "frac": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12 / mfma_peak(r["name"]), 4)} for r in same]
+        out["roofline_gemm"] = g
+    if samp_rows:
+        sr = roofline_sampler(samp_rows[0], traffic)
+        sr["total_ms"] = round(samp_rows[0]["total_ms"], 2)
+        out["roofline_sampler"] = sr
+    t_gemm = sum(r["total_ms"] for r in gemm_rows)
+    t_samp = samp_rows[0]["total_ms"] if samp_rows else 0.0
+    others = [r for r in rows if r not in gemm_rows and r not in samp_rows and r["total_ms"] > 0]
+    top_other = max(others, key=lambda r: r["total_ms"]) if others else None
+    if gemm_rows and t_gemm >= t_samp and (top_other is None or t_gemm >= top_other["total_ms"]):
+        out["roofline"] = dict(out["roofline_gemm"], dominant_class="gemm", class_share_of_kernel_time=round(
+            t_gemm / max(sum(r["total_ms"] for r in rows), 1e-9), 4))
+    elif samp_rows and (top_other is None or t_samp >= top_other["total_ms"]):
+        out["roofline"] = dict(out["roofline_sampler"], dominant_class="sampler", class_share_of_kernel_time=round(
+            t_samp / max(sum(r["total_ms"] for r in rows), 1e-9), 4))
+    elif top_other is not None:  # e.g. the encoder's convolutions on a tiny-N workload
+        out["roofline"] = dict(roofline_mfma(top_other["name"], [top_other], traffic, sustained), dominant_class="other")
+    return out
 
 
 def golden_parity(name, coords, vis_logit, conf_logit, coords_key="coords"):
@@ -256,6 +397,65 @@ def c2_parity(dev, precision):
     return golden_parity("c2", cap["coords"][0], vl[0], cl[0])
 
 
+def quick_line(name, dev, precision="f16x3", steps=2, warmup=1, feature_cache=False):
+    """One more workload timed in the same process after the headline (single GPU, no profile, no CPU leg): the same
+    barrier-free protocol -- `warmup` untimed steps, synchronize, `steps` timed steps, synchronize.  Used for the extra rows
+    of the driver-run JSON (`extra_lines`): the exact-f32 back end on the headline workload, BASELINE configs[1] (C2) and
+    configs[3] (C4, default = the reference's behaviour of re-encoding every chunk; the feature cache is a labelled opt-in)."""
+    from cotracker_amd import model as M
+    from cotracker_amd.predictor import CoTrackerOnlinePredictor, CoTrackerPredictor
+    from cotracker_amd.synthetic import synthetic_video
+    from cotracker_amd.weights import fill_synthetic_
+    H, W, T, G, offline, wl, desc = WORKLOADS[name]
+    old, M.DEFAULT_PRECISION = M.DEFAULT_PRECISION, precision
+    try:
+        if name == "c4_online":
+            pred = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
+            pred.model.hip_graph = True
+            pred.model.online_feature_cache = bool(feature_cache)
+            T = pred.step * (steps + warmup + 2)
+        else:
+            pred = CoTrackerPredictor(checkpoint=None, offline=offline, window_len=wl)
+    finally:
+        M.DEFAULT_PRECISION = old
+    fill_synthetic_(pred.model, seed=0)
+    pred = pred.to(dev)
+    video = synthetic_video(T, H, W, seed=1234).to(dev)
+    if name == "c4_online":
+        pred(video_chunk=video[:, :2 * pred.step], is_first_step=True, grid_size=G)
+        cur = [0]
+
+        def step():
+            i = cur[0]
+            cur[0] += pred.step
+            return pred(video_chunk=video[:, i:i + 2 * pred.step])
+        frames = pred.step
+    else:
+        def step():
+            return pred(video, grid_size=G)
+        frames = T
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out[0]).all()
+    finish = getattr(pred, "finish", None)
+    if finish is not None:
+        finish()  # resolve the deferred f16-range check of the last graph replay
+    line = {"workload": name, "precision": precision, "steps": steps, "warmup": warmup, "ms_per_step": round(sec * 1e3, 2),
+            "value": round(G * G * frames / sec, 1), "unit": "tracked-point-frames/s", "range_fallbacks": int(getattr(pred.model, "range_fallbacks", 0))}
+    if name == "c4_online":
+        line["online_feature_cache"] = bool(feature_cache)
+        line["hip_graph"] = True
+    del pred, video
+    torch.cuda.empty_cache()
+    return line
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -299,8 +499,8 @@ def main():
         from cotracker_amd.predictor import CoTrackerOnlinePredictor
         pred = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
         pred.model.hip_graph = not args.no_graph
-        # the workload's chunks overlap by window_len - step frames (predictor.py:288-290): opt in to re-using their features
-        pred.model.online_feature_cache = True
+        # the workload's chunks overlap by window_len - step frames (predictor.py:288-290); re-using their features is --feature-cache
+        pred.model.online_feature_cache = bool(args.feature_cache)  # default off = the reference's behaviour (every chunk re-encoded)
         T = pred.step * (args.steps + args.warmup + 3)  # one chunk call per step, plus the profiled call
     elif offline == "v2":
         pred = CoTrackerPredictor(checkpoint=None, v2=True, window_len=wl)
@@ -499,21 +699,26 @@ def main():
                                         "fresh": stamp == so_hash}
             if traffic.pop("_workload", "c3_sliding") != args.workload or stamp != so_hash:
                 traffic = {}  # the PMC passes were collected on another workload or another build of the kernels: bytes do not transfer
-        gemm_rows = [r for r in rows if r["name"].startswith(("gemm_sh", "gemm_f16x3", "gemm_f32", "mlp_sh"))]
-        if rows:
-            dom = rows[0]
-            result["roofline"] = roofline_sampler(dom, traffic) if dom["name"].startswith("corr_") else roofline_mfma(dom["name"], [dom], traffic)
-        if gemm_rows:
-            result["roofline_gemm"] = roofline_mfma("gemm (all Linear launches, call-weighted)", gemm_rows, traffic)
-            result["roofline_gemm"]["rows"] = [{"name": r["name"], "launches": r["launches"],
-                                                "avg_us": round(1e3 * r["total_ms"] / max(r["launches"], 1), 1),
-                                                "frac": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12 /
-                                                              (F16_MFMA_PEAK_TFLOPS / 3.0 if not r["name"].startswith("gemm_f32") else FP32_MFMA_PEAK_TFLOPS), 4)}
-                                               for r in gemm_rows if r["total_ms"] > 0]
-        for r in rows:
-            if r["name"].startswith("corr_"):
-                result["roofline_sampler"] = roofline_sampler(r, traffic)
-                break
+        sustained = None
+        try:
+            sustained = sustained_mfma(dev)
+            result["sustained_mfma"] = sustained
+        except Exception as e:  # a reported calibration, never a reason to lose the bench line
+            result["sustained_mfma"] = {"error": f"{type(e).__name__}: {e}"}
+        result.update(rooflines(rows, traffic, sustained))
+    if rank == 0 and world == 1 and args.workload == "c3_sliding" and args.precision == "f16x3" and not args.no_extra_lines:
+        # driver-timed versions of the numbers that used to exist only as builder-run files in profiles/ (<15 s together)
+        extra = {}
+        for key, kw in (("c3_sliding_f32", dict(name="c3_sliding", precision="f32", steps=2, warmup=1)),
+                        ("c2_offline", dict(name="c2_offline", steps=5, warmup=2)),
+                        ("c4_online", dict(name="c4_online", steps=12, warmup=3)),
+                        ("c4_online_feature_cache", dict(name="c4_online", steps=12, warmup=3, feature_cache=True))):
+            try:
+                extra[key] = quick_line(dev=dev, **kw)
+            except Exception as e:
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
+        result["extra_lines"] = extra
+        result["value_f32"] = extra["c3_sliding_f32"].get("value")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:

@@ -173,8 +173,8 @@ UfWs carve_uf(int S, int N, void* base) {
   w.att = take(R * CTK_HID);
   w.hid = take(R * CTK_MLP);
   w.partial = take((size_t)v2p_splits(N) * S * CTK_HEADS * CTK_VIRT * (CTK_HEAD_DIM + 2));
-  w.sk_bytes = ctk_pp_scratch_bytes();
-  w.sk = take((w.sk_bytes + 3) / 4);
+  w.sk_bytes = ctk_pp_scratch_bytes_if_enabled();  // 0 unless ctk_gemm_pp_mode bit 4 (stream-K) is set
+  w.sk = w.sk_bytes ? take((w.sk_bytes + 3) / 4) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -427,6 +427,7 @@ int check_window(const ctk_window_args* a) {
   if (!a) return CTK_E_NULL;
   if (a->S <= 0 || a->N <= 0 || a->iters < 0) return CTK_E_SHAPE;
   if ((long)(a->N + CTK_VIRT) * a->S > 2000000000L / CTK_MLP * 64) return CTK_E_SHAPE;
+  if (a->flags & ~CTK_WINDOW_NO_SPACE_ATTN) return CTK_E_SHAPE;  // unknown flag bits: a caller built the pre-v6 struct (no `flags`)
   return CTK_OK;
 }
 

@@ -68,6 +68,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s);
 // the call (thread-local; zeroes the flags on `s`).  Only launches on that stream use it; without one the kernels deal whole
 // tiles in rounds.
 size_t ctk_pp_scratch_bytes();
+size_t ctk_pp_scratch_bytes_if_enabled();
 struct CtkPPScratchScope {
   CtkPPScratchScope(void* mem, size_t bytes, hipStream_t s);
   ~CtkPPScratchScope();

@@ -598,6 +598,9 @@ thread_local hipStream_t t_sk_stream = nullptr;
 }  // namespace
 
 size_t ctk_pp_scratch_bytes() { return (size_t)PP_SK_FLAG_BYTES + (size_t)pp_num_cus() * PP_SK_SLOT_MAX; }
+// what a window / update-former workspace reserves for it: nothing unless the opt-in stream-K walk (mode bit 4) is on at
+// workspace-size query time (it was ~64 MiB per workspace and per captured graph for a default-off experiment)
+size_t ctk_pp_scratch_bytes_if_enabled() { return (g_pp_mode & 16) ? ctk_pp_scratch_bytes() : 0; }
 
 CtkPPScratchScope::CtkPPScratchScope(void* mem, size_t bytes, hipStream_t s) : prev_mem_(t_sk_mem), prev_bytes_(t_sk_bytes), prev_stream_(t_sk_stream) {
   if (mem && bytes >= ctk_pp_scratch_bytes() && (g_pp_mode & 16) != 0 && hipMemsetAsync(mem, 0, PP_SK_FLAG_BYTES, s) == hipSuccess) {
@@ -639,6 +642,13 @@ extern "C" int ctk_gemm_set_scratch(void* mem, size_t bytes, void* stream) {
   return CTK_OK;
 }
 
+// the compile-time epilogues the persistent kernels are instantiated for (the PP_CASE list below)
+static bool pp_epi_supported(int code) {
+  return code == pp_epi(CTK_ACT_GELU_ERF, false, true, false, true) || code == pp_epi(CTK_ACT_NONE, false, true, false, true) ||
+         code == pp_epi(CTK_ACT_NONE, false, false, true, false) || code == pp_epi(CTK_ACT_NONE, false, false, false, true) ||
+         code == pp_epi(CTK_ACT_NONE, true, false, false, true) || code == pp_epi(CTK_ACT_GELU_TANH, false, true, false, true);
+}
+
 // Returns CTK_OK after launching, or -1 when the shape is not one of the persistent kernels' (caller falls back).
 int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   if ((g_pp_mode & 1) == 0 || !g.a_split || !g.Wp) return -1;
@@ -646,17 +656,21 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   if ((!t256 && !t192) || g.N * 4 > PP_BIAS_BYTES) return -1;
   if (g.lda * 2 > 0xffffff) return -1;  // row offsets are formed with 32-bit arithmetic inside a tile
   const int BN = t256 ? 256 : 192;
-  g.mblocks = (g.M + 255) / 256;
-  g.nblocks = g.N / BN;
-  const long tiles = (long)g.mblocks * g.nblocks * g.batch;
+  const int mblocks = (g.M + 255) / 256, nblocks = g.N / BN;
+  const long tiles = (long)mblocks * nblocks * g.batch;
   const int cus = pp_num_cus();
   if (tiles < cus) return -1;  // less than one tile per CU (virtual-track GEMMs, short streaming windows): the 64x64 / 128x128 kernels fill the chip better (tools/gemm_lab.cpp)
-  char pname[40];
-  snprintf(pname, sizeof(pname), "gemm_sh_pp%d_k%d_n%d", BN, g.K, g.N);
-  CtkProfScope ps(pname, flops, bytes, s);
   const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), blk(512);
   const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
   if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
+  if (!pp_epi_supported(code)) return -1;
+  // every eligibility check is done: only now touch g and open the profile row (a fallback to gemm_f16x3.hip must not leave
+  // a phantom gemm_sh_pp* row or a changed tile grid behind)
+  g.mblocks = mblocks;
+  g.nblocks = nblocks;
+  char pname[40];
+  snprintf(pname, sizeof(pname), "gemm_sh_pp%d_k%d_n%d", BN, g.K, g.N);
+  CtkProfScope ps(pname, flops, bytes, s);
   // stream-K only on the stream whose entry point lent the scratch (one persistent GEMM at a time uses the slots)
   g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;
   const bool dbgk = (g_pp_mode & ~17) != 0;

@@ -129,9 +129,41 @@ __global__ __launch_bounds__(256) void probe_mfma_bf16_kernel(int iters, float* 
     for (int e = 0; e < 16; ++e) s += acc[i][e];
   if (s == 12345.678f) out[0] = s;
 }
+
+// kind 2: the instruction the split-half kernels issue (v_mfma_f32_32x32x16_f16) on pseudo-random normal-range halves,
+// four operand pairs in rotation, so operand-bus and multiplier toggling is that of real data (the constant operands
+// of kind 1 draw less power and hold a higher clock): the MFMA rate this chip SUSTAINS under its power cap.
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void probe_mfma_f16_random_kernel(int iters, float* out) {
+  pf32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  pf16x8 a[4], b[4];
+  unsigned x = 0x9E3779B9u * (threadIdx.x + 257u * blockIdx.x + 1u);
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 8; ++e) {
+      x = x * 1664525u + 1013904223u;
+      const unsigned short ha = (unsigned short)(((x >> 16) & 0x83ffu) | 0x3800u);  // sign + 10 random mantissa bits, |v| in [0.5, 1)
+      x = x * 1664525u + 1013904223u;
+      const unsigned short hb = (unsigned short)(((x >> 16) & 0x83ffu) | 0x3400u);  // |v| in [0.25, 0.5)
+      a[i][e] = __builtin_bit_cast(_Float16, ha);
+      b[i][e] = __builtin_bit_cast(_Float16, hb);
+    }
+  for (int it = 0; it < iters; it += 4) {  // (iters is rounded up to a multiple of 4 by the launcher)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[(i + j) & 3], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.678f) out[0] = s;
+}
 }  // namespace
 
-// kind 0: v_mfma_f32_32x32x2_f32, kind 1: v_mfma_f32_32x32x16_bf16.  Returns the flop count launched.
+// kind 0: v_mfma_f32_32x32x2_f32, kind 1: v_mfma_f32_32x32x16_bf16 (constant operands), kind 2: v_mfma_f32_32x32x16_f16 on
+// pseudo-random operands.  Returns the flop count launched.
 extern "C" int ctk_probe_mfma(int kind, int iters, float* scratch, double* flops, void* stream) {
   if (!scratch || !flops || iters <= 0) return CTK_E_NULL;
   const int blocks = 256 * 2;  // 2 workgroups of 4 waves per CU
@@ -139,9 +171,15 @@ extern "C" int ctk_probe_mfma(int kind, int iters, float* scratch, double* flops
   if (kind == 0) {
     hipLaunchKernelGGL(probe_mfma_f32_kernel, dim3(blocks), dim3(256), 0, s, iters, scratch);
     *flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * (2.0 * 32 * 32 * 2);
-  } else {
+  } else if (kind == 1) {
     hipLaunchKernelGGL(probe_mfma_bf16_kernel, dim3(blocks), dim3(256), 0, s, iters, scratch);
     *flops = (double)blocks * 4 * iters * 4.0 * (2.0 * 32 * 32 * 16);
+  } else if (kind == 2) {
+    iters = (iters + 3) & ~3;
+    hipLaunchKernelGGL(probe_mfma_f16_random_kernel, dim3(blocks), dim3(256), 0, s, iters, scratch);
+    *flops = (double)blocks * 4 * iters * 4.0 * (2.0 * 32 * 32 * 16);
+  } else {
+    return CTK_E_SHAPE;
   }
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;

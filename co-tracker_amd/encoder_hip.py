@@ -4,7 +4,7 @@ Strings ctk_conv2d_sh / ctk_enc_* together in the order of the reference (cotrac
 BasicEncoder.forward :184-219, ResidualBlock.forward :128-138) for the ``fnet`` of a model, reading its parameters
 (``fnet.*`` state_dict keys are unchanged: the weights are repacked per device, like the Linear layers).  No MIOpen, no
 torch convolution: torch only owns the memory.  Output = what ``model._encode`` produces with the torch encoder: the
-L2-normalised NHWC level-0 features [T, H/4, W/4, 128].
+L2-normalised NHWC level-0 features [T, H/4, W/4, 128] (``normalize=False``: the raw ``conv3`` output, what CoTracker2 tracks on).
 """
 import ctypes as C
 
@@ -42,8 +42,9 @@ class _Conv:
 
 
 class HipEncoder:
-    def __init__(self, fnet, device):
+    def __init__(self, fnet, device, normalize=True):
         self.device = device
+        self.normalize = bool(normalize)  # CoTracker3 L2-normalises the features (cotracker3_online.py:373-376); CoTracker2 does not
         self.stride = fnet.stride
         self.zeros = torch.zeros(64, device=device, dtype=torch.float32)
         self.conv1 = _Conv(fnet.conv1, device, stem=True)
@@ -138,5 +139,8 @@ class HipEncoder:
         if out is None:
             out = torch.empty(F, oh, ow, 128, device=self.device, dtype=torch.float32)
         assert out.shape == (F, oh, ow, 128) and out.is_contiguous()
-        L.check(lib.ctk_enc_l2norm(_ptr(z), F * oh * ow, _ptr(out), ops._stream()), "ctk_enc_l2norm")
+        if self.normalize:
+            L.check(lib.ctk_enc_l2norm(_ptr(z), F * oh * ow, _ptr(out), ops._stream()), "ctk_enc_l2norm")
+        else:
+            out.view(F * oh * ow, 128).copy_(z)
         return out

@@ -8,10 +8,11 @@ signature / return tuple, online-state methods and -- crucially -- the same ``st
 set, so reference checkpoints load unchanged and a reference ``CoTrackerPredictor`` can have its
 ``.model`` swapped for one of these.
 
-The CNN encoder runs on PyTorch-ROCm; everything after it (feature normalisation + pyramid,
-support sampling, and the 6x iterative update: correlation sampling, corr MLP, token
-assembly, EfficientUpdateFormer, state update) runs in the HIP library through
-``cotracker_amd.ops``.  Window scheduling and online state are Python glue, as in the reference.
+Everything numeric runs in the HIP library through ``cotracker_amd.ops`` / ``encoder_hip``: the CNN
+encoder (split-half implicit-GEMM convolutions, round 3; the PyTorch-ROCm / MIOpen encoder stays selectable
+with ``encoder_backend = "torch"`` for A/B), feature normalisation + pyramid, support sampling, and the 6x
+iterative update (correlation sampling, corr MLP, token assembly, EfficientUpdateFormer, state update).
+Window scheduling and online state are Python glue, as in the reference.
 Inference only (``is_train`` must be False).
 """
 import warnings
@@ -201,6 +202,23 @@ class PackedWeights:
 # ------------------------------------------------------------------------------------------
 # models
 # ------------------------------------------------------------------------------------------
+def tail_aliases(prev, cur, dim, step):
+    """True iff `cur` is the window of the SAME live allocation as `prev`, advanced by `step` entries along `dim` (so that
+    cur[..., :n-step, ...] and prev[..., step:, ...] are the same bytes) and nothing wrote to that allocation through a
+    tensor sharing its version counter in between.  Host-side metadata only: no kernel, no synchronisation.  The caller
+    must have kept `prev` alive since it was recorded (a freed allocation could be handed out again at the same address)."""
+    if prev is None or cur is None or prev.shape != cur.shape or prev.dtype != cur.dtype or prev.device != cur.device:
+        return False
+    if prev.stride() != cur.stride() or cur.shape[dim] <= step:
+        return False
+    try:
+        same = prev.untyped_storage().data_ptr() == cur.untyped_storage().data_ptr()
+    except Exception:  # storage-less tensors
+        return False
+    return bool(same and cur.storage_offset() == prev.storage_offset() + step * prev.stride(dim)
+                and getattr(prev, "_ctk_version", prev._version) == cur._version)
+
+
 class CoTrackerThreeBase(nn.Module):
     """Constructor mirrors cotracker3_online.py:43-92."""
 
@@ -287,10 +305,12 @@ class CoTrackerThreeBase(nn.Module):
 
     # device-side caches (ctypes structs with raw pointers) are rebuilt on demand: keep them out of pickles / deep copies
     _TRANSIENT = {"_packed": dict, "_graphs": dict, "_hip_encoder": type(None), "_pending_range": type(None), "_pending_overlap": type(None),
-                  "online_f0_tail": type(None), "_online_prev_frames": type(None)}
+                  "online_f0_tail": type(None), "_online_prev_frames": type(None), "_overlap_hint": type(None), "_hint_now": type(None)}
 
     def __getstate__(self):
-        self._resolve_deferred_range_check()  # a pending (pinned flag, cuda Event) pair cannot be pickled, and must not be lost
+        # a pending (pinned flag, cuda Event) pair cannot be pickled, and must not be lost: pickling (like deepcopy) a model in
+        # the middle of a graph stream waits for the last chunk and may raise FloatingPointError
+        self._resolve_deferred_range_check()
         st = self.__dict__.copy()
         for k, mk in self._TRANSIENT.items():
             if k in st:
@@ -300,9 +320,11 @@ class CoTrackerThreeBase(nn.Module):
     def __deepcopy__(self, memo):
         import copy
         cls = self.__class__
+        # may synchronise and raise FloatingPointError (a pending deferred range check of graph streaming): do it BEFORE the
+        # half-built copy is registered in memo, so a raise leaves no partial object behind
+        self._resolve_deferred_range_check()
         new = cls.__new__(cls)
         memo[id(self)] = new
-        self._resolve_deferred_range_check()
         for k, v in self.__dict__.items():
             new.__dict__[k] = self._TRANSIENT[k]() if k in self._TRANSIENT else copy.deepcopy(v, memo)
         return new
@@ -433,7 +455,8 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         self.online_vis_predicted = None
         self.online_conf_predicted = None
         self.online_f0_tail = None        # level-0 features of the frames the NEXT chunk starts with (feature cache)
-        self._online_prev_frames = None   # those frames themselves, to verify the overlap asynchronously
+        self._online_prev_frames = None   # the previous chunk itself (a reference), to prove the overlap on the host
+        self._overlap_hint = None         # the predictor's verdict for the NEXT call (it resizes chunks into fresh tensors)
         self._pending_overlap = None
         self._pending_range = None
         self._online_batch = None  # B > 1: one state tuple per batch element (the attributes above hold the last one run)
@@ -447,6 +470,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         if is_online:
             assert T <= S, "Online mode: video chunk must be <= window size."
             assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
+        self._hint_now, self._overlap_hint = getattr(self, "_overlap_hint", None), None
         # streaming with the window graph (CoTrackerOnlinePredictor): deferred range check, the chunk stream stays asynchronous
         deferred = bool(is_online and self.hip_graph and B == 1)
         run = lambda b: self._guarded(  # noqa: E731
@@ -485,20 +509,30 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
         """Streaming: consecutive chunks overlap by S - step frames (predictor.py:225,288-290 feeds the last 2*step frames
         every step), and the encoder is per-frame, so the overlapping frames' level-0 features are the ones computed one
         call ago.  With ``online_feature_cache`` (opt-in) only the `step` NEW frames go through the CNN (half the encoder
-        time of a streaming call).  That the overlapping frames really are the previous chunk's is verified on the device
-        BEFORE the cached features are used (one small device-to-host flag per call); a chunk that does not overlap is
-        simply encoded in full, exactly what the reference does with it."""
+        time of a streaming call) -- when the overlap is PROVEN ON THE HOST, with no device work and no synchronisation: the
+        new chunk's first S - step frames must be the very memory of the previous chunk's last S - step frames (same live
+        storage, offset advanced by `step` frames, same strides / dtype, tensor version unchanged: `tail_aliases`), which is
+        what slicing a resident video gives (``video[:, i:i + S]``, then ``video[:, i + step:i + step + S]``).
+        CoTrackerOnlinePredictor applies the same test to the chunk it is handed and passes the verdict down
+        (``_overlap_hint``), because it resizes every chunk into a fresh tensor.  A chunk whose overlap cannot be proven
+        that way is simply encoded in full, exactly what the reference does with it (round 3 compared the frames on the
+        device with torch.equal: a blocking device-to-host wait in every streaming call -- ADVICE r3)."""
         T = video.shape[0]
         ov = S - step
         tail, prev = self.online_f0_tail, self._online_prev_frames
-        if self.online_feature_cache and T == S and tail is not None and tail.shape[0] == ov and prev.shape == video[:ov].shape \
-                and bool(torch.equal(video[:ov], prev)):
+        hint = getattr(self, "_hint_now", None)  # the predictor's verdict for this forward call (all batch elements)
+        proven = hint if hint is not None else tail_aliases(prev, video, 0, step)
+        if self.online_feature_cache and T == S and tail is not None and tail.shape[0] == ov and proven:
             f0 = torch.cat([tail, self._encode(video[ov:].float(), chunk)], dim=0)
         else:
             f0 = self._encode(video.float(), chunk)
         if self.online_feature_cache and T == S:
             self.online_f0_tail = f0[step:]
-            self._online_prev_frames = video[step:].clone()
+            self._online_prev_frames = video  # a reference, not a copy: keeps the storage alive, so "same address" means "same allocation"
+            try:
+                video._ctk_version = video._version  # the version the cached features were computed from
+            except Exception:
+                pass
         else:
             self.online_f0_tail = self._online_prev_frames = None
         return f0

@@ -61,6 +61,17 @@ class CoTracker2(nn.Module):
         self._graphs = {}
         from . import model as _m
         self.precision = _m.DEFAULT_PRECISION  # Linear back end: "f16x3" (split-half MFMA) | "f32"; not a reference kwarg
+        # f16 range guard of the split-half back end, as CoTrackerThreeBase (model.py): every forward checks its outputs once;
+        # a non-finite result re-runs that forward on the exact-f32 back end (offline / sliding: immediately; graph streaming:
+        # the flag is examined at the start of the next call and raises -- see _guarded).  range_fallbacks counts hits.
+        self.range_guard = True
+        self.range_fallbacks = 0
+        self._pending_range = None
+        # "hip" (default): BasicEncoder on the library's split-half implicit-GEMM convolutions (encoder_hip.py), without the
+        # final L2 normalisation CoTracker3 applies; "torch": nn.Conv2d on PyTorch-ROCm / MIOpen (A/B).  Not a reference kwarg.
+        self.encoder_backend = "hip"
+        self.encoder_chunk = 16
+        self._hip_encoder = None
 
 
 # ------------------------------------------------------------------------------------------
@@ -186,6 +197,7 @@ def _v2_graphed_window(self, pyr, coords, track_feat, vis, track_mask, point_mas
 
 
 def _v2_init_online(self):  # cotracker.py:187-191
+    self._resolve_deferred_range_check()  # the last chunk of the previous stream (graph streaming defers its check by one call)
     self.online_ind = 0
     self.online_track_feat = None
     self.online_coords_predicted = None
@@ -208,14 +220,37 @@ def _v2_forward(self, video, queries, iters=4, is_train=False, is_online=False):
         if B != 1:
             raise NotImplementedError("online mode supports B=1")
     self._online_active = bool(is_online)
-    outs = [self._forward_one(video[b], queries[b], iters, is_online) for b in range(B)]
-    return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), None
+    deferred = bool(is_online and self.hip_graph)  # graph streaming: the chunk stream never waits for the GPU
+    snap = (self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted) if is_online else None
+
+    def restore(st):
+        self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted = st
+
+    outs = [self._guarded(lambda prec, b=b: self._forward_one(video[b], queries[b], iters, is_online, prec), snap, restore, deferred)
+            for b in range(B)]
+    self.last_logits = (torch.stack([o[1] for o in outs]),)  # pre-sigmoid visibility [B,T,N] (parity tests compare logits)
+    return torch.stack([o[0] for o in outs]), torch.sigmoid(self.last_logits[0]), None
 
 
-def _v2_forward_one(self, video, queries, iters, is_online):
+def _v2_encode(self, frames):
+    """frames [T,3,H,W] in 0..255 -> NHWC level-0 features [T,H/4,W/4,128], NOT normalised (cotracker.py:273-275)."""
+    if self.encoder_backend == "hip":
+        enc = self._hip_encoder
+        if enc is None or enc.device != frames.device:
+            from .encoder_hip import HipEncoder
+            enc = self._hip_encoder = HipEncoder(self.fnet, frames.device, normalize=False)
+        T, _, H, W = frames.shape
+        out = torch.empty(T, H // self.stride, W // self.stride, self.latent_dim, device=frames.device, dtype=torch.float32)
+        for t0 in range(0, T, self.encoder_chunk):
+            enc(frames[t0:t0 + self.encoder_chunk].float().contiguous(), out=out[t0:t0 + self.encoder_chunk])
+        return out
+    return self.fnet(2 * (frames.float() / 255.0) - 1.0).float().permute(0, 2, 3, 1).contiguous()
+
+
+def _v2_forward_one(self, video, queries, iters, is_online, precision=None):
     T, N = video.shape[0], queries.shape[0]
     S, step, dev = self.window_len, self.window_len // 2, video.device
-    pw = self.packed(dev)
+    pw = self.packed(dev, precision)
     queries = queries.float()
     qframes = queries[:, 0].long()
     qcoords = (queries[:, 1:3] / self.stride).contiguous()
@@ -227,7 +262,7 @@ def _v2_forward_one(self, video, queries, iters, is_online):
         vis_pred = F.pad(self.online_vis_predicted, (0, 0, 0, p))
     # encoder; padding the video with its last frame (:264-270) == repeating the last feature map (fnet is per-frame)
     pad = (S - T) if is_online else (S - T % S) % S
-    f0 = self.fnet(2 * (video.float() / 255.0) - 1.0).float().permute(0, 2, 3, 1).contiguous()  # NHWC, not normalised
+    f0 = self._encode(video)  # NHWC, not normalised
     if pad > 0:
         f0 = torch.cat([f0, f0[-1:].expand(pad, -1, -1, -1)], dim=0).contiguous()
     pyr = ops.build_pyramid(f0, 4)  # CorrBlock pyramid (blocks.py:300-307) for every frame at once
@@ -272,17 +307,22 @@ def _v2_forward_one(self, video, queries, iters, is_online):
         self.online_ind += step
         self.online_coords_predicted = coords_pred
         self.online_vis_predicted = vis_pred
-    return coords_pred, torch.sigmoid(vis_pred)
+    return coords_pred, vis_pred  # (visibility LOGITS: forward applies the sigmoid, cotracker.py:373)
 
 
-def _v2_packed(self, device):
-    if self._packed is None or self._packed.device != device or self._packed.precision != self.precision:
-        self._packed = PackedWeightsV2(self, device, self.precision)
-    return self._packed
+def _v2_packed(self, device, precision=None):
+    precision = precision or self.precision
+    if not isinstance(self._packed, dict):
+        self._packed = {}
+    pw = self._packed.get(precision)
+    if pw is None or pw.device != device:
+        pw = self._packed[precision] = PackedWeightsV2(self, device, precision)
+    return pw
 
 
 def _v2_invalidate(self):
     self._packed = None
+    self._hip_encoder = None
     if getattr(self, "_graphs", None):
         if torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()
@@ -299,19 +339,25 @@ def _v2_apply(self, fn, *args, **kwargs):
     return nn.Module._apply(self, fn, *args, **kwargs)
 
 
+_V2_TRANSIENT = {"_packed": type(None), "_graphs": dict, "_hip_encoder": type(None), "_pending_range": type(None)}
+
+
 def _v2_getstate(self):  # the packed-weight cache holds ctypes structs with raw pointers: never pickled / deep-copied
+    self._resolve_deferred_range_check()  # may wait for the last streamed chunk and raise FloatingPointError (as model.py)
     st = self.__dict__.copy()
-    st["_packed"] = None
-    st["_graphs"] = {}
+    for k, mk in _V2_TRANSIENT.items():
+        if k in st:
+            st[k] = mk()
     return st
 
 
 def _v2_deepcopy(self, memo):
     import copy
+    self._resolve_deferred_range_check()  # before the copy is registered in memo: a raise leaves nothing half-built behind
     new = self.__class__.__new__(self.__class__)
     memo[id(self)] = new
     for k, v in self.__dict__.items():
-        new.__dict__[k] = None if k == "_packed" else ({} if k == "_graphs" else copy.deepcopy(v, memo))
+        new.__dict__[k] = _V2_TRANSIENT[k]() if k in _V2_TRANSIENT else copy.deepcopy(v, memo)
     return new
 
 
@@ -322,6 +368,10 @@ CoTracker2._graphed_window = _v2_graphed_window
 CoTracker2.init_video_online_processing = _v2_init_online
 CoTracker2.forward = _v2_forward
 CoTracker2._forward_one = _v2_forward_one
+CoTracker2._encode = _v2_encode
+from .model import CoTrackerThreeBase as _Base  # noqa: E402  (the range guard is the same code for both model families)
+CoTracker2._guarded = _Base._guarded
+CoTracker2._resolve_deferred_range_check = _Base._resolve_deferred_range_check
 CoTracker2.packed = _v2_packed
 CoTracker2.invalidate_packed_weights = _v2_invalidate
 CoTracker2.load_state_dict = _v2_load_state_dict

@@ -174,6 +174,7 @@ class CoTrackerOnlinePredictor(torch.nn.Module):
         ih, iw = self.interp_shape
         if is_first_step:  # predictor.py:242-274: reset state, remember the queries, no tracking yet
             self.model.init_video_online_processing()
+            self._prev_chunk = None
             if queries is not None:
                 assert queries.shape[2] == 3
                 self.N = queries.shape[1]
@@ -189,6 +190,18 @@ class CoTrackerOnlinePredictor(torch.nn.Module):
             self.queries = queries
             return (None, None)
 
+        # streaming feature cache (opt-in, model.online_feature_cache): prove ON THE HOST that this chunk's first T - step frames
+        # are the memory of the previous chunk's last T - step frames (a view of the same resident video advanced by `step`
+        # frames) and tell the model -- it only ever sees the freshly resized tensor below.  No device work, no wait.
+        if getattr(self.model, "online_feature_cache", False):
+            from .model import tail_aliases
+            prev = getattr(self, "_prev_chunk", None)
+            self.model._overlap_hint = bool(tail_aliases(prev, video_chunk, 1, self.step))
+            self._prev_chunk = video_chunk  # a reference: keeps the allocation alive until the next call
+            try:
+                video_chunk._ctk_version = video_chunk._version
+            except Exception:
+                pass
         v = F.interpolate(video_chunk.reshape(B * T, C, H, W).float(), tuple(self.interp_shape), mode="bilinear",
                           align_corners=True).reshape(B, T, 3, ih, iw)
         if self.v2:  # CoTracker2 returns (tracks, visibility, train_data): no confidence (predictor.py:283-286)

@@ -60,3 +60,23 @@ def fill_synthetic_(module: torch.nn.Module, seed: int = 0, head_scale: float = 
     if inval is not None:  # cotracker_amd models cache device-side repacked weights
         inval()
     return module
+
+
+# CoTracker2 at BASELINE scale (tests/golden/make_golden_scale.py "v2_c2", tests/test_gpu_scale.py): with xavier-random weights
+# the CoTracker2 update (coordinates AND track features fed back through 6 + 6 transformer layers, cotracker.py:131-171) is a
+# chaotic map -- the unmodified reference moves 0.76 px between 8 and 3 CPU threads at the CoTracker3 head scale and 0.08 px at
+# 0.25 x -- so six iterations can only be pinned with a damped feedback: flow-head scale 0.02 and track_feat_updater x 0.1
+# (reference 8 vs 3 threads: ~1e-4 px; the tracks still move up to ~3 px per window).
+V2_DAMP = {"head_scale": 0.02, "updater_scale": 0.1}
+
+
+@torch.no_grad()
+def fill_synthetic_v2_damped_(module: torch.nn.Module, seed: int = 0):
+    """fill_synthetic_ for a CoTracker2 (reference or cotracker_amd) with the V2_DAMP feedback damping."""
+    fill_synthetic_(module, seed=seed, head_scale=V2_DAMP["head_scale"])
+    module.track_feat_updater[0].weight.mul_(V2_DAMP["updater_scale"])
+    module.track_feat_updater[0].bias.mul_(V2_DAMP["updater_scale"])
+    inval = getattr(module, "invalidate_packed_weights", None)
+    if inval is not None:
+        inval()
+    return module

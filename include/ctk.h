@@ -129,7 +129,9 @@ typedef struct ctk_window_args {
                                  their inputs are unchanged; only their stream differs).  Must not be the capture-origin
                                  of another graph; safe inside ctk_window_graph_create (it joins that capture).  */
   int32_t flags;              /* CTK_WINDOW_NO_SPACE_ATTN: EfficientUpdateFormer.forward(add_space_attn=False) -- only the time
-                                 blocks run, the virtual tracks are still appended and stripped (cotracker.py:496-502,521-523) */
+                                 blocks run, the virtual tracks are still appended and stripped (cotracker.py:496-502,521-523).
+                                 MUST be 0 otherwise: every entry point taking this struct returns CTK_E_SHAPE when an
+                                 unknown bit is set (a caller that built the pre-v6 struct hands over 4 bytes of garbage) */
 } ctk_window_args;
 #define CTK_WINDOW_NO_SPACE_ATTN 1
 
@@ -416,7 +418,9 @@ int ctk_profile_enable(int on);
 void ctk_gemm_pp_mode(int mode);
 int ctk_profile_read(ctk_profile_row* rows, int max_rows, int* nrows);
 /* Register-only MFMA loop (2 workgroups x 4 waves per CU) to calibrate the sustained peak of this
- * chip under its power budget: kind 0 = v_mfma_f32_32x32x2_f32, 1 = v_mfma_f32_32x32x16_bf16.     */
+ * chip under its power budget: kind 0 = v_mfma_f32_32x32x2_f32, 1 = v_mfma_f32_32x32x16_bf16 (constant operands),
+ * 2 = v_mfma_f32_32x32x16_f16 on pseudo-random operands (the instruction and the toggle activity of the split-half
+ * kernels: bench.py's `sustained_mfma` figure).  Any other kind: CTK_E_SHAPE.                                   */
 int ctk_probe_mfma(int kind, int iters, float* scratch, double* flops, void* stream);
 
 #ifdef __cplusplus

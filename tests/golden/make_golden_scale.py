@@ -9,6 +9,8 @@ Workloads are bench.py's (same synthetic video seed 1234, same ``fill_synthetic_
   c4      BASELINE configs[3]: CoTrackerOnlinePredictor(window_len=16), 512x512, grid 32 (N=1024), 5 chunk calls (T=48)
   c3_g40  BASELINE configs[2] video (512x512, T=120), CoTrackerPredictor(offline=False, window_len=16), grid 40 (N=1600)
   c3_g80  BASELINE configs[2] exactly: grid 80 (N=6400), 14 windows x 6 iterations, jointly tracked
+  v2_c2   SURVEY 8f-3: CoTrackerPredictor(v2=True, window_len=8) (hub recipe cotracker2), 512x512, T=48, grid 20, 6 iterations,
+          damped feedback (cotracker_amd.weights.V2_DAMP; conf_logit duplicates vis_logit: CoTracker2 has no confidence head)
 Stored per workload (OUTPUTS ONLY -- inputs and weights are regenerated from seeds on both sides):
   coords  [T,N,2]  model-level tracks in model-resolution pixels (model.forward()[0])
   vis_logit / conf_logit [T,N]  PRE-sigmoid (the argument of the reference's own torch.sigmoid call, captured by wrapping
@@ -32,7 +34,7 @@ sys.path.insert(0, "/root/reference")
 
 from cotracker.predictor import CoTrackerPredictor, CoTrackerOnlinePredictor  # noqa: E402
 
-from cotracker_amd.weights import fill_synthetic_  # noqa: E402
+from cotracker_amd.weights import fill_synthetic_, fill_synthetic_v2_damped_  # noqa: E402
 from cotracker_amd.synthetic import synthetic_video  # noqa: E402
 
 CONFIGS = {
@@ -55,6 +57,14 @@ CONFIGS = {
     # configs[4], the per-GPU unit of work: chunk 0 (8 779 points) of the 265x265 quasi-dense grid, explicit queries at
     # frame 0, sliding windows (bench.py --workload c5_shard, rank 0); every 4th point is stored
     "c5_chunk0": (512, 512, 120, 265, "chunk0", 16, 8, 5),
+    # round 4: CoTracker2 at BASELINE scale -- hub recipe cotracker2 (CoTrackerPredictor(v2=True, window_len=8)),
+    # the reference's default 6 iterations per window, 11 sliding windows.  With xavier-random weights the CoTracker2 map
+    # (coordinates AND track features fed back through 6 + 6 transformer layers) is chaotic: the reference itself moves
+    # 0.76 px / 0.75 logit between 8 and 3 CPU threads at the CoTracker3 head scale, 0.08 px with heads x0.25, and damping the
+    # feature path or the residual branches does not help (heads x0.25, updater x0 : still 0.06 px) -- the coordinate feedback
+    # drives it.  cotracker_amd.weights.V2_DAMP (flow-head scale 0.02 instead of 8, track_feat_updater x0.1) makes six iterations reproducible
+    # (8 vs 3 threads: ~1e-4 px) while every stage still runs on non-trivial data (tracks move up to ~3 px per window).
+    "v2_c2": (512, 512, 48, 20, "v2", 8, 8, 3),
 }
 STORE_EVERY = {"c3_g80": 4, "c5_chunk0": 4}  # jointly tracked, every k-th point stored (fixture size)
 
@@ -99,9 +109,14 @@ def run(name, threads):
     captured = {}
     if kind == "online":
         p = CoTrackerOnlinePredictor(checkpoint=None, window_len=wl)
+    elif kind == "v2":
+        p = CoTrackerPredictor(checkpoint=None, v2=True, window_len=wl)
     else:
         p = CoTrackerPredictor(checkpoint=None, offline=(kind == "offline"), window_len=wl)  # "sliding" / "queries": online weights
-    fill_synthetic_(p.model, seed=0)
+    if kind == "v2":
+        fill_synthetic_v2_damped_(p.model, seed=0)  # cotracker_amd.weights.V2_DAMP: heads x 0.02 (instead of 8), updater x 0.1
+    else:
+        fill_synthetic_(p.model, seed=0)
     model_forward = p.model.forward
 
     def tap_forward(*a, **k):
@@ -131,7 +146,10 @@ def run(name, threads):
         else:
             tracks, vis = p(video, grid_size=G)
     dt = time.time() - t0
-    vis_logit, conf_logit = tap.args[-2], tap.args[-1]  # the last two sigmoid calls are the returned vis / conf (queries: of the backward pass)
+    if kind == "v2":  # CoTracker2 has no confidence head: ONE sigmoid, on the visibility logits (cotracker.py:373); stored twice
+        vis_logit = conf_logit = tap.args[-1]
+    else:
+        vis_logit, conf_logit = tap.args[-2], tap.args[-1]  # the last two sigmoid calls are the returned vis / conf (queries: of the backward pass)
     out = dict(coords=captured["coords"][0], vis_logit=vis_logit[0].reshape(vis_logit.shape[1], -1),
                conf_logit=conf_logit[0].reshape(conf_logit.shape[1], -1), tracks=tracks[0], vis=vis[0])
     out = {k: v.cpu().numpy() for k, v in out.items()}
