@@ -549,7 +549,7 @@ def main():
             tap["coords"] = o[0].clone()
             return o
 
-        if world == 1:
+        if rank == 0:  # rank 0 tracks chunk 0 whatever the world size: its timed step is checked against scale_c5_chunk0
             pred.model.forward = tapped
 
         def local_step():
@@ -649,7 +649,7 @@ def main():
         parity = {}
         golden_name = {"c3_sliding": "c3_g80", "c2_offline": "c2", "c1_standin": "c1", "c3_offline_g40": "c3_off",
                        "c5_shard": "c5_chunk0"}.get(args.workload)
-        if world == 1 and golden_name and getattr(pred.model, "last_logits", None) is not None:
+        if (world == 1 or c5) and golden_name and getattr(pred.model, "last_logits", None) is not None:
             vl, cl = pred.model.last_logits
             gp = golden_parity(golden_name, tap["coords"][0], vl[0], cl[0], coords_key="coords")
             if gp:

@@ -19,7 +19,8 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
+PAD_ZEROS, PAD_BORDER = 0, 1  # ctk_bilinear_sampler padding_mode
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -146,6 +147,8 @@ SYMBOLS = {
     "ctk_v2_apply_delta": (C.c_int, [C.c_int32, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, C.c_float, _fp, _fp]),
     "ctk_v2_vis_head": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "ctk_sample_features4d": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp, _fp]),
+    "ctk_bilinear_sampler": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int64, C.c_int32,
+                                       C.c_int32, _fp, _fp]),
     "ctk_tap_indices": (C.c_int, [_P(WindowArgs), _fp, _fp]),
     "ctk_sample_patches": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, C.c_int32, _fp, _fp]),
     "ctk_sample_support": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, _fp, _fp]),

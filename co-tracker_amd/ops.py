@@ -219,6 +219,32 @@ def sample_features4d(map_hwc: torch.Tensor, coords: torch.Tensor) -> torch.Tens
     return out
 
 
+def bilinear_sampler(input: torch.Tensor, coords: torch.Tensor, align_corners: bool = True, padding_mode: str = "border") -> torch.Tensor:
+    """Op D: bilinear_sampler (model_utils.py:191-255), the reference's signature and layouts -- input [B,C,H,W] with coords
+    [B,Ho,Wo,2] = (x, y) -> [B,C,Ho,Wo], or input [B,C,T,H,W] with coords [B,Do,Ho,Wo,3] = (t, x, y) -> [B,C,Do,Ho,Wo].
+    Bit-identical to the reference's F.grid_sample on the CPU (ctk_bilinear_sampler, csrc/sampler.hip)."""
+    _chk_f32(input, coords)
+    if padding_mode not in ("zeros", "border"):
+        raise NotImplementedError(f"padding_mode={padding_mode!r}: the HIP sampler implements 'zeros' and 'border'")
+    sizes = input.shape[2:]
+    assert len(sizes) in (2, 3), "input must be [B,C,H,W] or [B,C,T,H,W]"
+    nd = len(sizes)
+    assert coords.dim() == nd + 2 and coords.shape[-1] == nd and coords.shape[0] == input.shape[0]
+    B, Cc = input.shape[:2]
+    D = sizes[0] if nd == 3 else 0
+    H, W = sizes[-2], sizes[-1]
+    inner = tuple(coords.shape[1:-1])
+    P = 1
+    for d in inner:
+        P *= d
+    out = torch.empty((B, Cc) + inner, device=input.device, dtype=torch.float32)
+    if P > 0:
+        L.check(L.load().ctk_bilinear_sampler(_ptr(input.contiguous()), B, Cc, D, H, W, _ptr(coords.contiguous()), P, int(bool(align_corners)),
+                                              L.PAD_BORDER if padding_mode == "border" else L.PAD_ZEROS, _ptr(out), _stream()),
+                "ctk_bilinear_sampler")
+    return out
+
+
 def v2_assemble(coords, fcorrs, track_feat, track_mask, vis, pos, in_ld: int, out_split: bool) -> torch.Tensor:
     """Transformer input of CoTracker2 (cotracker.py:135-150 without the time embedding): [N*S, in_ld] f32 or SH."""
     _chk_f32(coords, fcorrs, track_feat, track_mask, vis, pos)

@@ -26,28 +26,38 @@ def shard_queries(queries: torch.Tensor, world: int, rank: int) -> torch.Tensor:
     return queries[:, lo:hi]
 
 
-def all_gather_tracks(tracks: torch.Tensor, vis: torch.Tensor, n_total: int, group=None):
-    """tracks [B,T,n_r,2], vis [B,T,n_r] of this rank -> ([B,T,N,2], [B,T,N]) on every rank.
+def all_gather_tracks(tracks: torch.Tensor, vis: torch.Tensor, n_total: int, group=None, conf: torch.Tensor = None):
+    """tracks [B,T,n_r,2], vis [B,T,n_r] (+ optionally conf [B,T,n_r]) of this rank -> ([B,T,N,2], [B,T,N](, [B,T,N])) on
+    every rank.
 
-    Chunks are padded to ceil(N/world) so a single fixed-size all_gather (ncclAllGather under the
-    "nccl" backend = RCCL) suffices; on the fully connected xGMI topology that is one hop per peer.
+    ONE fixed-size collective: every rank packs its chunk POINT-MAJOR into [per, B, T, C] (per = ceil(N/world), C = 3 or 4
+    floats: x, y, visibility(, confidence)), `all_gather_into_tensor` (ncclAllGather under the "nccl" backend = RCCL; one hop
+    per peer on the fully connected xGMI topology) fills a preallocated [world*per, B, T, C] buffer, and the results are
+    permuted VIEWS of that buffer -- no list of per-rank tensors, no torch.cat, no second full-size copy (round 3 had both).
+    The returned tensors are therefore not contiguous; call .contiguous() if a consumer needs that.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return tracks, vis
+        return (tracks, vis) if conf is None else (tracks, vis, conf)
     per = (n_total + world - 1) // world
-    B, T = tracks.shape[:2]
-    packed = torch.zeros(B, T, per, 3, device=tracks.device, dtype=torch.float32)
-    n_r = tracks.shape[2]
-    packed[:, :, :n_r, :2] = tracks
-    packed[:, :, :n_r, 2] = vis.to(torch.float32)
-    out = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(out, packed.contiguous(), group=group)
-    full = torch.cat(out, dim=2)[:, :, :n_total]
+    B, T, n_r = tracks.shape[:3]
+    C = 3 if conf is None else 4
+    packed = torch.zeros(per, B, T, C, device=tracks.device, dtype=torch.float32)
+    packed[:n_r, :, :, :2] = tracks.permute(2, 0, 1, 3)
+    packed[:n_r, :, :, 2] = vis.to(torch.float32).permute(2, 0, 1)
+    if conf is not None:
+        packed[:n_r, :, :, 3] = conf.to(torch.float32).permute(2, 0, 1)
+    full = torch.empty(world * per, B, T, C, device=tracks.device, dtype=torch.float32)
+    try:
+        dist.all_gather_into_tensor(full, packed, group=group)
+    except (RuntimeError, NotImplementedError):  # a backend without the flat all-gather: per-rank VIEWS of the same buffer
+        dist.all_gather([full[r * per:(r + 1) * per] for r in range(world)], packed, group=group)
+    full = full[:n_total].permute(1, 2, 0, 3)  # [B,T,N,C] view
     vis_full = full[..., 2]
     if vis.dtype == torch.bool:
         vis_full = vis_full > 0.5
-    return full[..., :2].contiguous(), vis_full
+    out = (full[..., :2], vis_full)
+    return out if conf is None else out + (full[..., 3],)
 
 
 def track_sharded(predictor, video: torch.Tensor, queries: torch.Tensor, group=None, **kwargs):

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTK_ABI_VERSION 7
+#define CTK_ABI_VERSION 8
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -222,6 +222,18 @@ int ctk_v2_apply_delta(int32_t S, int32_t N, const float* delta, int32_t out_ld,
 int ctk_v2_vis_head(const float* track_feat, int64_t R, const float* w, const float* b, float* out, void* stream);
 int ctk_sample_features4d(const float* map, int32_t H, int32_t W, int32_t C, const float* coords, int32_t N, float* out,
                           void* stream);
+
+/* ---- Op D: the stand-alone bilinear_sampler with the reference's FULL signature (model_utils.py:191-255) ----
+ * input  [B,C,H,W] (D = 0) with coords [B,P,2] = (x, y), or [B,C,D,H,W] (D > 0) with coords [B,P,3] = (t, x, y), both in
+ *        the reference's own NCHW layout; P = product of the coords' inner dims (Ho*Wo, or Do*Ho*Wo);
+ * align_corners 0 / 1, padding_mode CTK_PAD_ZEROS / CTK_PAD_BORDER ("reflection": CTK_E_SHAPE);  out [B,C,P].
+ * Bit-identical to torch.nn.functional.grid_sample on the CPU for finite coordinates (4-D: ATen's vectorised kernel with its
+ * FMA contractions; 5-D: the scalar grid_sampler_3d -- csrc/sampler_math.h), NaN coordinates are not specified.
+ * Also what sample_features4d / sample_features5d (model_utils.py:258-323) reduce to (cotracker_amd/model_utils.py).     */
+#define CTK_PAD_ZEROS 0
+#define CTK_PAD_BORDER 1
+int ctk_bilinear_sampler(const float* input, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, const float* coords,
+                         int64_t P, int32_t align_corners, int32_t padding_mode, float* out, void* stream);
 
 /* ---- CoTracker2 window driver: CoTracker2.forward_window (cotracker.py:86-173) as ONE capture-safe call per window
  * (the CoTracker2 counterpart of ctk_forward_window): sampled positional embedding once, then `iters` x { CorrBlock

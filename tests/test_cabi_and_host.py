@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SYMBOLS), f"binding/header mismatch: {declared ^ set(_lib.SYMBOLS)}"
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_argument_validation_without_gpu(lib):
@@ -87,6 +87,32 @@ def test_struct_sizes_match_header(tmp_path):
     for n, cls in pairs.items():
         assert C.sizeof(cls) == int(out[n]), (n, C.sizeof(cls), out[n])
     assert C.sizeof(L.BlockWeights) == 17 * 8
+
+
+def test_integration_md_binding_stub_matches_the_header():
+    """the ctypes mirror INTEGRATION.md tells a maintainer to write must be the struct the library reads --
+    round 3's stub stopped at aux_stream (168 bytes) while ctk_forward_window reads `flags` at offset 168 of 176.  The stub is
+    executed as written and compared with the typed binding, field by field; unknown flag bits are refused by the library."""
+    import re
+    from cotracker_amd import _lib as L
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# cotracker/models/core/cotracker/_ctk_binding\.py.*?)```", md, re.S).group(1)
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    stub = ns["ctk_window_args"]
+    assert C.sizeof(stub) == C.sizeof(L.WindowArgs) == 176
+    assert [(n, getattr(stub, n).offset, getattr(stub, n).size) for n, _ in stub._fields_] == \
+           [(n, getattr(L.WindowArgs, n).offset, getattr(L.WindowArgs, n).size) for n, _ in L.WindowArgs._fields_]
+    assert f"ctk_abi_version() == {L.ABI_VERSION}" in block
+    lib = L.load()
+    a = L.WindowArgs()
+    a.S, a.N, a.iters = 8, 4, 1
+    nb = C.c_size_t()
+    assert lib.ctk_forward_window_workspace_bytes(C.byref(a), C.byref(nb)) == 0
+    a.flags = 2  # an unknown bit (what garbage past a short struct looks like)
+    assert lib.ctk_forward_window_workspace_bytes(C.byref(a), C.byref(nb)) == -2  # CTK_E_SHAPE
+    a.flags = L.WINDOW_NO_SPACE_ATTN
+    assert lib.ctk_forward_window_workspace_bytes(C.byref(a), C.byref(nb)) == 0
 
 
 def test_no_product_import_of_oracle():

@@ -502,6 +502,108 @@ def test_corrblock_vs_oracle_stress():
 # ------------------------------------------------------------------------------------------
 # models and predictors (encoder on PyTorch-ROCm + HIP hot path) vs reference goldens
 # ------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------
+# Op D: the stand-alone bilinear_sampler with the reference's full signature (model_utils.py:191-255)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pad", ["border", "zeros"])
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("nd", [2, 3])
+def test_bilinear_sampler_bit_exact_vs_grid_sample(nd, align, pad):
+    """ctk_bilinear_sampler (HIP) against what the reference computes on the CPU -- F.grid_sample after model_utils.py's
+    coordinate scaling -- BIT FOR BIT: 4-D and 5-D inputs, both align_corners conventions, both padding modes, coordinates
+    inside / on / far outside the image, exact integers and half-integers, degenerate 1-pixel axes."""
+    from cotracker_amd.model_utils import bilinear_sampler
+    from test_sampler_math_host import ref_bilinear_sampler, _coords
+    g = torch.Generator().manual_seed(100 * nd + 10 * int(align) + (pad == "zeros"))
+    for sizes in ([(12, 16), (1, 5), (7, 1), (96, 128)] if nd == 2 else [(5, 12, 16), (1, 9, 7), (3, 1, 4), (16, 24, 32)]):
+        inp = torch.randn((2, 19) + sizes, generator=g)   # 19 channels: a partial last channel group
+        c = torch.stack([_coords(g, 4096, sizes, nd) for _ in range(2)])
+        coords = c.view(2, 64, 64, nd) if nd == 2 else c.view(2, 16, 16, 16, nd)
+        ref = ref_bilinear_sampler(inp, coords, align, pad)
+        out = bilinear_sampler(inp.to(dev()), coords.to(dev()), align_corners=align, padding_mode=pad).cpu()
+        assert out.shape == ref.shape
+        bad = (out.view(torch.int32) != ref.view(torch.int32)) & ~((out == 0) & (ref == 0))
+        assert int(bad.sum()) == 0, (sizes, int(bad.sum()), maxdiff(out, ref))
+
+
+def test_bilinear_sampler_reference_unit_test_on_the_hip_kernel():
+    """The reference's only unit test (tests/test_bilinear_sample.py:16-47: identity sampling, 4-D and 5-D, both conventions)
+    replayed against the HIP kernel (round 3 replayed it against the CPU oracle only)."""
+    from cotracker_amd.model_utils import bilinear_sampler
+    for align in (True, False):
+        H, W = 4, 5
+        inp = torch.randn(H * W).view(1, 1, H, W).float()
+        coords = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        coords = torch.stack(coords[::-1], dim=-1).float()[None]
+        if not align:
+            coords = coords + 0.5
+        torch.testing.assert_close(inp, bilinear_sampler(inp.to(dev()), coords.to(dev()), align_corners=align).cpu())
+        T = 3
+        vid = torch.stack([inp, inp + 1, inp + 2], dim=2)
+        c5 = torch.meshgrid(torch.arange(T), torch.arange(W), torch.arange(H), indexing="ij")
+        c5 = torch.stack(c5, dim=-1).float().permute(0, 2, 1, 3)[None]
+        if not align:
+            c5 = c5 + 0.5
+        torch.testing.assert_close(vid, bilinear_sampler(vid.to(dev()), c5.to(dev()), align_corners=align).cpu())
+    with pytest.raises(NotImplementedError):
+        bilinear_sampler(inp.to(dev()), coords.to(dev()), padding_mode="reflection")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        bilinear_sampler(inp, coords)
+
+
+def test_sample_features_4d_5d_match_reference_semantics(golden):
+    """sample_features4d / sample_features5d (model_utils.py:258-323) through Op D == the reference's formulas on the CPU, and
+    == the fused support sampler of the hot path on the real pyramid (ops.npz: bit-exact both ways)."""
+    from cotracker_amd.model_utils import sample_features4d, sample_features5d
+    from test_sampler_math_host import ref_bilinear_sampler
+    g = torch.Generator().manual_seed(8)
+    fm = torch.randn(2, 128, 24, 32, generator=g)
+    c = torch.rand(2, 50, 2, generator=g) * torch.tensor([33.0, 25.0]) - 1.0
+    ref = ref_bilinear_sampler(fm, c.unsqueeze(2)).permute(0, 2, 1, 3).reshape(2, 50, 128)
+    assert torch.equal(sample_features4d(fm.to(dev()), c.to(dev())).cpu(), ref)
+    vid = torch.randn(1, 6, 128, 12, 16, generator=g)   # B T C H W
+    c5 = torch.cat([torch.rand(1, 7, 9, 1, generator=g) * 6 - 0.5, torch.rand(1, 7, 9, 1, generator=g) * 17 - 1,
+                    torch.rand(1, 7, 9, 1, generator=g) * 13 - 1], dim=-1)
+    ref5 = ref_bilinear_sampler(vid.permute(0, 2, 1, 3, 4), c5.unsqueeze(3)).permute(0, 2, 3, 1, 4).reshape(1, 7, 9, 128)
+    assert torch.equal(sample_features5d(vid.to(dev()), c5.to(dev())).cpu(), ref5)
+
+
+@pytest.mark.parametrize("which", ["online", "offline", "cotracker2"])
+def test_encoder_hip_vs_reference_fnet(golden, which):
+    """SURVEY 8f-4, stage level: BasicEncoder.forward (blocks.py:141-219) on the HIP implicit-GEMM convolutions against the
+    `fnet` outputs the UNMODIFIED reference produced on CPU (stored by tests/golden/make_golden.py next to the model-level
+    goldens): raw conv3 output <= 5e-6 (relative to the feature scale), the L2-normalised pyramid level CoTracker3 tracks on
+    <= 2e-6 absolute, and -- the property the determinism gates rest on -- the same bits whatever the batch a frame sits in."""
+    from cotracker_amd.encoder_hip import HipEncoder
+    from cotracker_amd.weights import fill_synthetic_
+    if which == "cotracker2":
+        from cotracker_amd.model_v2 import CoTracker2
+        g = golden("cotracker2")
+        m = CoTracker2(stride=4, window_len=8, model_resolution=(64, 96)).eval()
+        fill_synthetic_(m, seed=6, head_scale=1.0)
+        video, ref = t(g["video"])[0], g["fmaps"][0]
+    else:
+        from cotracker_amd.model import CoTrackerThreeOnline, CoTrackerThreeOffline
+        g = golden(f"model_{which}")
+        cls, seed, key = (CoTrackerThreeOnline, 1, "on") if which == "online" else (CoTrackerThreeOffline, 2, "off")
+        m = cls(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96)).eval()
+        fill_synthetic_(m, seed=seed)
+        video, ref = t(g[f"{key}_video"])[0], g[f"{key}_fnet"]
+    m = m.to(dev())
+    ref = torch.from_numpy(np.ascontiguousarray(np.transpose(ref, (0, 2, 3, 1))))  # NCHW -> NHWC
+    raw = HipEncoder(m.fnet, dev(), normalize=False)(video.float().contiguous())
+    scale = float(ref.abs().max())
+    assert raw.shape == ref.shape and maxdiff(raw, ref) <= 5e-6 * max(1.0, scale), (maxdiff(raw, ref), scale)
+    nrm = HipEncoder(m.fnet, dev())(video.float().contiguous())
+    ref_n = ref.double() / torch.sqrt(torch.maximum((ref.double() ** 2).sum(-1, keepdim=True), torch.tensor(1e-12, dtype=torch.float64)))
+    assert maxdiff(nrm, ref_n) <= 2e-6, maxdiff(nrm, ref_n)   # cotracker3_online.py:373-376
+    # per-frame determinism: a frame's features do not depend on the batch it is encoded in, or on its position in it
+    enc = HipEncoder(m.fnet, dev())
+    one = torch.cat([enc(video[i:i + 1].float().contiguous()) for i in (3, 0)])
+    assert torch.equal(one[0], nrm[3]) and torch.equal(one[1], nrm[0])
+    assert torch.equal(enc(video[2:7].float().contiguous()), nrm[2:7])
+
+
 def test_model_online_sliding_and_streaming(golden):
     from cotracker_amd.model import CoTrackerThreeOnline
     from cotracker_amd.weights import fill_synthetic_

@@ -35,6 +35,14 @@ def _worker(rank, world, port, n, out):
     tr, vi = track_sharded(_stub_predictor, video, q)
     ref_t, ref_v = _stub_predictor(video, queries=q)
     ok = torch.allclose(tr, ref_t) and torch.equal(vi, ref_v) and tr.shape == (1, 5, n, 2)
+    # the optional confidence column rides in the same collective (online predictor: visibility * confidence upstream)
+    from cotracker_amd.sharding import all_gather_tracks, chunk_bounds
+    lo, hi = chunk_bounds(n, world, rank)
+    conf_ref = ref_t[..., 0] * 0.01
+    tr3, vi3, cf3 = all_gather_tracks(ref_t[:, :, lo:hi], ref_v[:, :, lo:hi], n, conf=conf_ref[:, :, lo:hi])
+    ok = ok and torch.equal(tr3, ref_t) and torch.equal(vi3, ref_v) and torch.equal(cf3, conf_ref) and vi3.dtype == torch.bool
+    # ONE buffer: tracks / visibility / confidence are views of the same gathered allocation (no cat, no second copy)
+    ok = ok and tr3.untyped_storage().data_ptr() == cf3.untyped_storage().data_ptr()
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -1,49 +1,70 @@
 #!/bin/bash
-# One gpurun call: parity tests, headline bench, streaming bench, rocprofv3 kernel stats + PMC traffic passes.
-# Everything lands in gpurun_out/.  Usage: tools/gpu_session.sh [tests|bench|prof|all ...]
+# Round-4 GPU session: tools/gpu_session.sh [tests] [bench] [more] [prof] [pmc] [sq] [lab]   (default: tests bench)
+# One gpurun call = one box: everything wanted from it is listed here; outputs go to gpurun_out/r04_*.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-WHAT="${*:-all}"
-has() { [[ " $WHAT " == *" $1 "* || " $WHAT " == *" all "* ]]; }
-
+R=r04
+WHAT="${*:-tests bench}"
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+summ() {  # summ <tag> <json>
+  python - "$1" "$2" <<'PY'
+import json, sys
+tag, f = sys.argv[1:3]
+try:
+    d = json.load(open(f))
+    print(tag, d["value"], d["ms_per_step"], "ms; parity:", json.dumps(d.get("parity"))[:600])
+    if tag == "c3":
+        for k in d.get("kernels", [])[:28]: print("   ", k)
+        for key in ("roofline", "roofline_gemm", "roofline_sampler", "sustained_mfma", "extra_lines", "cpu_baseline"):
+            v = d.get(key) or {}
+            print(key, {k: x for k, x in v.items() if k not in ("note", "traffic_detail", "traffic_note", "reference_in_build_container", "sample", "rows")})
+        for r in (d.get("roofline_gemm") or {}).get("rows", []): print("      ", r)
+except Exception as e:
+    print(tag, "parse failed", e)
+    try: print(open(f.replace(".json", ".err")).read()[-3000:])
+    except Exception: pass
+PY
+}
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    cd /tmp && rm -rf /tmp/pmc_$c && rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-extra-lines > /tmp/pmc_$c.log 2>&1
+    cd $GRAFT_REPO_ROOT
+  done
+  ff=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py "$ff" "$fw" gpurun_out/${R}_pmc_traffic.json c3_sliding > gpurun_out/${R}_pmc_traffic.txt 2>&1
+  head -30 gpurun_out/${R}_pmc_traffic.txt
+  cp gpurun_out/${R}_pmc_traffic.json profiles/pmc_traffic.json  # (on the box: the bench lines below attach it; its library hash is this build's)
+fi
+if has lab; then
+  (timeout 600 tools/gemm_lab 2>&1 | tail -20) | tee gpurun_out/${R}_gemm_lab.log
+fi
 if has tests; then
-  (timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -40) > gpurun_out/pytest_gpu.log
-  tail -15 gpurun_out/pytest_gpu.log
+  (timeout 2400 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -60) > gpurun_out/${R}_pytest_gpu.log
+  tail -45 gpurun_out/${R}_pytest_gpu.log
 fi
 if has bench; then
-  (timeout 600 python bench.py --steps 3 --warmup 1 2>gpurun_out/bench.err | tail -1) > gpurun_out/bench_c3.json
-  (timeout 300 python bench.py --workload c4_online --steps 12 --warmup 3 --no-cpu-baseline 2>gpurun_out/bench_c4.err | tail -1) > gpurun_out/bench_c4_graph.json
-  (timeout 300 python bench.py --workload c4_online --steps 12 --warmup 3 --no-cpu-baseline --no-graph --no-profile 2>>gpurun_out/bench_c4.err | tail -1) > gpurun_out/bench_c4_nograph.json
-  (timeout 300 python bench.py --workload c2_offline --steps 5 --warmup 2 --no-cpu-baseline 2>gpurun_out/bench_c2.err | tail -1) > gpurun_out/bench_c2.json
-  (timeout 300 python bench.py --workload c3_offline --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/bench_c3off.err | tail -1) > gpurun_out/bench_c3_offline.json
-  (timeout 300 python bench.py --workload v2_sliding --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/bench_v2.err | tail -1) > gpurun_out/bench_v2_sliding.json
-  python - <<'PY'
-import json
-for f in ("bench_c3", "bench_c4_graph", "bench_c4_nograph", "bench_c2", "bench_c3_offline", "bench_v2_sliding"):
-    try:
-        d = json.load(open(f"gpurun_out/{f}.json"))
-        print(f, d["value"], d["ms_per_step"], d.get("parity"), d.get("cpu_baseline", {}).get("value"))
-        for k in d.get("kernels", []): print("   ", k)
-        print("   roofline", {k: v for k, v in d.get("roofline", {}).items() if k != "note"})
-    except Exception as e:
-        print(f, "parse failed", e)
-PY
-  tail -5 gpurun_out/bench.err gpurun_out/bench_c4.err
+  (timeout 900 python bench.py --steps 5 --warmup 2 2>gpurun_out/${R}_bench_c3.err | tail -1) > gpurun_out/${R}_bench_c3.json
+  summ c3 gpurun_out/${R}_bench_c3.json
+fi
+if has more; then
+  for w in c2_offline c4_online c5_shard c3_offline c3_offline_g40 c1_standin v2_sliding; do
+    st=3; wu=1; [[ $w == c4_online ]] && { st=12; wu=3; }; [[ $w == c5_shard || $w == c3_offline* || $w == v2_sliding ]] && st=2
+    (timeout 600 python bench.py --workload $w --steps $st --warmup $wu --no-cpu-baseline 2>gpurun_out/${R}_bench_$w.err | tail -1) > gpurun_out/${R}_bench_$w.json
+    summ $w gpurun_out/${R}_bench_$w.json
+  done
+  (timeout 900 python bench.py --gpus 2 --single-device --dist-backend gloo --workload c5_shard --steps 1 --warmup 1 --no-cpu-baseline --no-profile 2>gpurun_out/${R}_bench_2rank.err | tail -1) > gpurun_out/${R}_bench_2rank_gloo_single_device_c5.json
+  summ 2rank_c5 gpurun_out/${R}_bench_2rank_gloo_single_device_c5.json
 fi
 if has prof; then
-  cd /tmp
-  R=$GRAFT_REPO_ROOT
-  CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile"
-  (cd $R && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- $CMD > $R/gpurun_out/prof_stats.log 2>&1)
-  CMD0="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile"
-  (cd $R && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- $CMD0 > $R/gpurun_out/prof_fetch.log 2>&1)
-  (cd $R && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- $CMD0 > $R/gpurun_out/prof_write.log 2>&1)
-  cd $R
-  python tools/summarize_rocprof.py gpurun_out/prof_stats gpurun_out/rocprof_kernel_stats.txt | head -30
-  F=$(ls -t $(find gpurun_out/prof_fetch -name "*counter_collection.csv") | head -1)
-  W=$(ls -t $(find gpurun_out/prof_write -name "*counter_collection.csv") | head -1)
-  python tools/pmc_traffic.py "$F" "$W" gpurun_out/pmc_traffic.json
-  # keep only the small summaries (raw traces are large)
-  find gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write -name '*kernel_trace.csv' -delete
-  du -sh gpurun_out
+  cd /tmp && rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extra-lines > /tmp/prof_bench.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/summarize_rocprof.py /tmp/prof gpurun_out/${R}_rocprof_kernel_stats.txt 2>&1 | tail -3
+  tail -5 /tmp/prof_bench.log | cut -c1-300
+  head -34 gpurun_out/${R}_rocprof_kernel_stats.txt
+fi
+if has sq; then
+  cd /tmp && rm -rf /tmp/sq /tmp/ldsc
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d /tmp/sq -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-extra-lines > /tmp/sq.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/summarize_counters.py /tmp/sq gpurun_out/${R}_sq_counters.txt | head -24
 fi
