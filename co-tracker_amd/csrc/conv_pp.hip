@@ -18,6 +18,7 @@
 // K-tiles; the per-lane pixel decode stays per tile), so the ring is idle at a tile's end and serves as the epilogue's
 // transpose scratch.
 #include "pp_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -34,7 +35,7 @@ constexpr int CV_RING = 3 * CV_SLOT;    // 144 KiB
 constexpr int CV_BIAS = 147456;         // bias (<= 4 KiB) behind the ring
 
 template <int EPI>
-__global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_total) {
+__global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_total, const bool conv_force_ph1) {
   constexpr bool DBG = false;
   constexpr int BM = 256, BN = 128;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS_ALL];
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_t
     const int nb = tile % g.nblocks;
     const int mb = tile / g.nblocks;
     const int m0 = mb * BM, n0 = nb * BN;
+    const bool ph1 = (p.n_valid - n0 > 64) || conv_force_ph1;  // workgroup-uniform: does the second 64-column phase carry stored columns?
 
     // ---- per-lane decode of my A rows: first block pieces 3w+e (e < 3), second block pieces 24 + 3w + e while 3w + e < 8
     int pix[6], iyx[6];  // pixel index of (f, 0, 0) in the input; packed (iy0 + 0x4000) << 16 | (ix0 + 0x4000)
@@ -178,24 +180,33 @@ __global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_t
             acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][0], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       PP_BARRIER();
-      // ---- phase 1: read B_1; request the rest of K-tile kt+2; K-tile kt+1 must have landed
+      // ---- phase 1: read B_1; request the rest of K-tile kt+2; K-tile kt+1 must have landed.
+      //      Round 4: a tile whose columns 64..127 are all zero-padded weight rows (the 64-channel layers: the stem and the four
+      //      convolutions of layer1, the largest-M launches of the encoder) skips this phase's fragment reads and its 12 MFMAs --
+      //      their products were multiplied by zero weights and never stored.  The DMA requests, waits and barriers stay exactly
+      //      as they are (every wave keeps issuing 6 pieces per K-tile: the counted vmcnt waits depend on it), so the schedule
+      //      tools/check_pp_schedule.py proves is unchanged; same bits out.
+      if (ph1) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl] + 8192);
+          for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl] + 8192);
+      }
       issue_i1(kt + 2, slot2);
       PP_WAIT_VM(6);
       PP_BARRIER();
-      PP_WAIT_LGKM0();
-      __builtin_amdgcn_s_setprio(1);
+      if (ph1) {
+        PP_WAIT_LGKM0();
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+          for (int term = 0; term < 3; ++term)
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][1], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+            for (int mi = 0; mi < 2; ++mi)
+              acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
       if (kt + 1 < KT) PP_BARRIER();
       slot = slot == 2 ? 0 : slot + 1;
     }
@@ -252,7 +263,8 @@ extern "C" int ctk_conv2d_sh(const void* in_sh, int32_t F, int32_t Hin, int32_t 
   snprintf(pname, sizeof(pname), "conv_pp128_%dx%d_s%d_c%d_n%d", KH, KW, stride, Cin, n_out);
   const double flops = 2.0 * M * (double)n_out * g.K;
   CtkProfScope ps(pname, flops, 4.0 * ((double)F * Hin * Win * Cin + (double)M * n_out), s);
-  hipLaunchKernelGGL((conv_pp128_kernel<32>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p, (int)tiles);
+  static const bool force_ph1 = [] { const char* e = getenv("CTK_CONV_PH1"); return e && atoi(e) == 1; }();  // dev A/B knob (read once): 1 = round-3 behaviour
+  hipLaunchKernelGGL((conv_pp128_kernel<32>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p, (int)tiles, force_ph1);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }

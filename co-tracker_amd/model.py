@@ -76,9 +76,10 @@ class _CrossBlock(nn.Module):  # cotracker.py:534-557
 
 
 class _UpdateFormerParams(nn.Module):  # cotracker.py:387-462
-    def __init__(self, input_dim=1110, hidden=384, depth=3, num_virtual_tracks=64, flow_out=2, vis_conf_head=True):
-        """CoTracker3: flow_head(2) + vis_conf_head(2) (linear_layer_for_vis_conf=True); CoTracker2: one flow_head of
-        output_dim = 130 and no vis_conf_head (cotracker.py:413-417)."""
+    def __init__(self, input_dim=1110, hidden=384, depth=3, num_virtual_tracks=64, flow_out=2, vis_conf_head=True, space_attn=True):
+        """CoTracker3: flow_head(2) + vis_conf_head(2) (linear_layer_for_vis_conf=True) or one flow_head(4) (False);
+        CoTracker2: one flow_head of output_dim = 130 and no vis_conf_head (cotracker.py:410-414).  space_attn=False
+        (constructor add_space_attn=False): the three space block lists do not exist, as in cotracker.py:432-460."""
         super().__init__()
         self.input_transform = _Lin(input_dim, hidden)
         self.flow_head = _Lin(hidden, flow_out)
@@ -88,6 +89,8 @@ class _UpdateFormerParams(nn.Module):  # cotracker.py:387-462
             nn.init.trunc_normal_(self.vis_conf_head.weight, std=0.001)
         self.virual_tracks = nn.Parameter(torch.randn(1, num_virtual_tracks, 1, hidden))  # (sic) reference key
         self.time_blocks = nn.ModuleList([_AttnBlock(hidden) for _ in range(depth)])
+        if not space_attn:
+            return
         self.space_virtual_blocks = nn.ModuleList([_AttnBlock(hidden) for _ in range(depth)])
         self.space_point2virtual_blocks = nn.ModuleList([_CrossBlock(hidden) for _ in range(depth)])
         self.space_virtual2point_blocks = nn.ModuleList([_CrossBlock(hidden) for _ in range(depth)])
@@ -155,8 +158,12 @@ class PackedWeights:
         st.in_w = hold(in_w)
         st.in_p = pack(in_w)
         st.virtual_tokens = hold(sd[u + "virual_tracks"].reshape(64, 384))
-        st.head_w = hold(torch.cat([sd[u + "flow_head.weight"], sd[u + "vis_conf_head.weight"]], dim=0))
-        st.head_b = hold(torch.cat([sd[u + "flow_head.bias"], sd[u + "vis_conf_head.bias"]], dim=0))
+        if u + "vis_conf_head.weight" in sd:  # linear_layer_for_vis_conf=True: two heads, concatenated (cotracker.py:526-529)
+            st.head_w = hold(torch.cat([sd[u + "flow_head.weight"], sd[u + "vis_conf_head.weight"]], dim=0))
+            st.head_b = hold(torch.cat([sd[u + "flow_head.bias"], sd[u + "vis_conf_head.bias"]], dim=0))
+        else:                                  # linear_layer_for_vis_conf=False: ONE Linear(384, 4) = the same [4,384] matrix
+            assert sd[u + "flow_head.weight"].shape == (4, 384)
+            st.head_w, st.head_b = hold(sd[u + "flow_head.weight"]), hold(sd[u + "flow_head.bias"])
 
         def block(prefix: str, attn_name: str, cross: bool) -> L.BlockWeights:
             b = L.BlockWeights()
@@ -173,8 +180,17 @@ class PackedWeights:
                 b.ctx_beta = hold(sd[prefix + "norm_context.bias"])
             return b
 
+        has_space = f"{u}space_virtual_blocks.0.attn.to_q.weight" in sd
         for i in range(L.DEPTH):
             st.time_blocks[i] = block(f"{u}time_blocks.{i}.", "attn", False)
+            if not has_space:
+                # constructor add_space_attn=False: the model has no space blocks and every window runs with
+                # CTK_WINDOW_NO_SPACE_ATTN, which never dereferences these slots; ctk_forward_window still validates them, so
+                # they alias the time block (norm_context of the cross slots: any 384 floats)
+                st.virtual_self[i] = st.virtual2point[i] = st.point2virtual[i] = st.time_blocks[i]
+                st.virtual2point[i].ctx_gamma = st.point2virtual[i].ctx_gamma = st.time_blocks[i].bq
+                st.virtual2point[i].ctx_beta = st.point2virtual[i].ctx_beta = st.time_blocks[i].bq
+                continue
             st.virtual_self[i] = block(f"{u}space_virtual_blocks.{i}.", "attn", False)
             st.virtual2point[i] = block(f"{u}space_virtual2point_blocks.{i}.", "cross_attn", True)
             st.point2virtual[i] = block(f"{u}space_point2virtual_blocks.{i}.", "cross_attn", True)
@@ -225,10 +241,12 @@ class CoTrackerThreeBase(nn.Module):
     def __init__(self, window_len=8, stride=4, corr_radius=3, corr_levels=4, num_virtual_tracks=64,
                  model_resolution=(384, 512), add_space_attn=True, linear_layer_for_vis_conf=True):
         super().__init__()
-        if (corr_radius, corr_levels, num_virtual_tracks) != (3, 4, 64) or not add_space_attn \
-                or not linear_layer_for_vis_conf:
-            raise NotImplementedError("HIP path is specialised to corr_radius=3, corr_levels=4, 64 virtual tracks, "
-                                      "space attention on (build_cotracker.py:31-38); see INTEGRATION.md")
+        if (corr_radius, corr_levels, num_virtual_tracks) != (3, 4, 64):
+            raise NotImplementedError("the HIP kernels are specialised to corr_radius=3 (7x7 taps), corr_levels=4 and 64 virtual "
+                                      "tracks -- the shapes every released model has (build_cotracker.py:31-38); see INTEGRATION.md")
+        # constructor add_space_attn=False (cotracker.py:432: no space blocks at all) and linear_layer_for_vis_conf=False
+        # (cotracker.py:413-414: one flow_head of width 4) are supported since round 4: same kernels, different parameter set
+        self.add_space_attn = bool(add_space_attn)
         self.window_len = window_len
         self.stride = stride
         self.corr_radius = corr_radius
@@ -240,7 +258,8 @@ class CoTrackerThreeBase(nn.Module):
         self.input_dim = 1110
         self.linear_layer_for_vis_conf = linear_layer_for_vis_conf
         self.fnet = BasicEncoder(input_dim=3, output_dim=self.latent_dim, stride=stride)
-        self.updateformer = _UpdateFormerParams(self.input_dim, 384, 3, num_virtual_tracks)
+        self.updateformer = _UpdateFormerParams(self.input_dim, 384, 3, num_virtual_tracks, flow_out=2 if linear_layer_for_vis_conf else 4,
+                                                vis_conf_head=bool(linear_layer_for_vis_conf), space_attn=bool(add_space_attn))
         self.corr_mlp = _Mlp(49 * 49, 384, 256)
         self.register_buffer("time_emb", sincos_time_embed(self.input_dim, window_len))
         self._packed = {}  # precision -> PackedWeights
@@ -433,7 +452,8 @@ class CoTrackerThreeBase(nn.Module):
     def _check_inputs(self, video, queries, is_train, add_space_attn=True):
         if is_train:
             raise NotImplementedError("inference-only implementation (training is out of scope)")
-        self._space_attn = bool(add_space_attn)  # forward-time flag of the reference (cotracker.py:496-502): time blocks only
+        # forward-time flag of the reference (cotracker.py:496-502: `add_space_attn and hasattr(self, "space_virtual_blocks")`)
+        self._space_attn = bool(add_space_attn) and getattr(self, "add_space_attn", True)
         if not video.is_cuda:
             raise RuntimeError("cotracker_amd runs on an MI355X GPU only: move the model and inputs to 'cuda'. "
                                "There is no CPU path.")

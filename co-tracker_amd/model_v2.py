@@ -224,7 +224,8 @@ def _v2_forward(self, video, queries, iters=4, is_train=False, is_online=False):
     snap = (self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted) if is_online else None
 
     def restore(st):
-        self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted = st
+        if st is not None:  # (offline / sliding: no online state to put back before the exact-f32 re-run)
+            self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted = st
 
     outs = [self._guarded(lambda prec, b=b: self._forward_one(video[b], queries[b], iters, is_online, prec), snap, restore, deferred)
             for b in range(B)]

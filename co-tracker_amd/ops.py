@@ -223,6 +223,7 @@ def bilinear_sampler(input: torch.Tensor, coords: torch.Tensor, align_corners: b
     """Op D: bilinear_sampler (model_utils.py:191-255), the reference's signature and layouts -- input [B,C,H,W] with coords
     [B,Ho,Wo,2] = (x, y) -> [B,C,Ho,Wo], or input [B,C,T,H,W] with coords [B,Do,Ho,Wo,3] = (t, x, y) -> [B,C,Do,Ho,Wo].
     Bit-identical to the reference's F.grid_sample on the CPU (ctk_bilinear_sampler, csrc/sampler.hip)."""
+    input, coords = input.contiguous(), coords.contiguous()  # (the reference's own unit test hands over permuted coordinates)
     _chk_f32(input, coords)
     if padding_mode not in ("zeros", "border"):
         raise NotImplementedError(f"padding_mode={padding_mode!r}: the HIP sampler implements 'zeros' and 'border'")
@@ -239,7 +240,7 @@ def bilinear_sampler(input: torch.Tensor, coords: torch.Tensor, align_corners: b
         P *= d
     out = torch.empty((B, Cc) + inner, device=input.device, dtype=torch.float32)
     if P > 0:
-        L.check(L.load().ctk_bilinear_sampler(_ptr(input.contiguous()), B, Cc, D, H, W, _ptr(coords.contiguous()), P, int(bool(align_corners)),
+        L.check(L.load().ctk_bilinear_sampler(_ptr(input), B, Cc, D, H, W, _ptr(coords), P, int(bool(align_corners)),
                                               L.PAD_BORDER if padding_mode == "border" else L.PAD_ZEROS, _ptr(out), _stream()),
                 "ctk_bilinear_sampler")
     return out

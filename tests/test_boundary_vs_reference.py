@@ -58,6 +58,10 @@ CASES = [  # (reference module key, class name, ours, kwargs)
     ("online", "CoTrackerThreeOnline", "cotracker_amd.model", dict(window_len=16)),
     ("offline", "CoTrackerThreeOffline", "cotracker_amd.model", dict(window_len=60)),
     ("v2", "CoTracker2", "cotracker_amd.model_v2", dict(window_len=8)),
+    # round 4: the two constructor variants that only change the PARAMETER SET (same kernels) -- cotracker3_online.py:43-53
+    ("online", "CoTrackerThreeOnline", "cotracker_amd.model", dict(window_len=16, linear_layer_for_vis_conf=False)),
+    ("offline", "CoTrackerThreeOffline", "cotracker_amd.model", dict(window_len=60, add_space_attn=False)),
+    ("online", "CoTrackerThreeOnline", "cotracker_amd.model", dict(window_len=16, add_space_attn=False, linear_layer_for_vis_conf=False)),
 ]
 
 
@@ -72,7 +76,12 @@ def test_state_dict_and_signatures_match_reference(ref, key, cls, ours_mod, kw):
     assert set(rs.keys()) == set(os_.keys())
     for k in rs:
         assert rs[k].shape == os_[k].shape and rs[k].dtype == os_[k].dtype, k
-    assert len(rs) == (321 if key == "v2" else 188)
+    if not any(k in kw for k in ("add_space_attn", "linear_layer_for_vis_conf")):
+        assert len(rs) == (321 if key == "v2" else 188)
+    if kw.get("add_space_attn") is False:
+        assert not any(".space_" in k for k in os_)
+    if kw.get("linear_layer_for_vis_conf") is False:
+        assert os_["updateformer.flow_head.weight"].shape == (4, 384) and not any("vis_conf_head" in k for k in os_)
     # deterministic buffers carry the same values (sin/cos tables built independently)
     for k in ("time_emb", "pos_emb"):
         if k in rs:

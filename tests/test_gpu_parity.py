@@ -622,11 +622,26 @@ def test_model_online_sliding_and_streaming(golden):
     assert maxdiff(cs, g["on_stream_coords"]) < 1e-3
     assert maxdiff(logit(vs), logit(g["on_stream_vis"])) < 1e-4
     assert maxdiff(logit(fs), logit(g["on_stream_conf"])) < 1e-4
-    # reference self-consistency: streaming == sliding, BIT FOR BIT, as in the reference on CPU.  Every kernel
-    # of the path (HIP encoder included: per-frame, fixed accumulation order whatever the batch) is deterministic and blind
-    # to where a frame sits in its batch, so the two modes hand identical inputs to identical launches.
-    assert maxdiff(cs, c) == 0.0, maxdiff(cs, c)
-    assert torch.equal(vs, v) and torch.equal(fs, f)
+    # Streaming vs sliding.  The two modes are NOT bit-identical in the reference when a query sits at a frame t > 0: its track
+    # feature is sampled trilinearly at (t, x, y) from a D-frame stack (D = padded video length when sliding, D = window length
+    # when streaming), and bilinear_sampler's coordinate round trip t * f32(2/(D-1)) - 1 -> ((g+1)/2)*(D-1) is not the identity
+    # (model_utils.py:242-251 + ATen grid_sampler_3d), so the frame weights (1, 0) become e.g. (1 - 5e-7, 5e-7) for one D and not
+    # the other.  The golden itself says so: the unmodified reference's on_coords and on_stream_coords differ by 8.4e-5 px
+    # (351 of 400 values).  Ours must differ between the modes by no more than the reference does (x3 for reduction order) ...
+    ref_gap = maxdiff(torch.from_numpy(g["on_coords"]), g["on_stream_coords"])
+    assert 1e-5 < ref_gap < 2e-4
+    assert maxdiff(cs, c) <= 3 * ref_gap, (maxdiff(cs, c), ref_gap)
+    # ... and be BIT-IDENTICAL where the reference is (checked against the imported reference in the build container: 0.0):
+    # all queries at frame 0, whose time coordinate survives the round trip exactly.  Every kernel of the path (HIP encoder
+    # included) is deterministic and blind to a frame's position in its batch, so both modes hand identical inputs to identical
+    # launches.  (Round 3 allowed 2e-4 px here and blamed MIOpen.)
+    q0 = q.clone()
+    q0[..., 0] = 0
+    c0, v0, f0_, _ = m(video, q0, iters=4)
+    m.init_video_online_processing()
+    for ind in range(0, video.shape[1] - 4, 4):
+        cs0, vs0, fs0, _ = m(video[:, ind:ind + 8], q0, iters=4, is_online=True)
+    assert torch.equal(cs0, c0) and torch.equal(vs0, v0) and torch.equal(fs0, f0_), maxdiff(cs0, c0)
 
 
 def test_window_graph_replay_is_bit_identical(golden, ops_model):
@@ -753,6 +768,41 @@ def test_model_add_space_attn_false_matches_time_blocks_only(golden):
     assert torch.isfinite(time_only).all() and torch.equal(time_only, again)
     assert maxdiff(full, time_only) > 1e-3          # the space blocks do something
     assert torch.equal(m(video, q, iters=2)[0], full)   # and the flag does not stick
+
+
+def test_constructor_variants_vis_conf_head_and_no_space_blocks(golden):
+    """cotracker3_online.py:43-53 variants that change only the parameter set: linear_layer_for_vis_conf=False (ONE
+    flow_head of width 4 = the two heads stacked, cotracker.py:410-414,526-529) and constructor add_space_attn=False (no
+    space blocks exist, cotracker.py:432-460; every forward is the time-blocks-only former).  Each must equal, bit for bit,
+    the standard model carrying the same numbers; the other three kwargs still raise."""
+    from cotracker_amd.model import CoTrackerThreeOffline
+    from cotracker_amd.weights import fill_synthetic_
+    g = golden("model_offline")
+    video, q = t(g["off_video"]), t(g["off_queries"])
+    kw = dict(stride=4, corr_radius=3, window_len=8, model_resolution=(64, 96))
+    std = CoTrackerThreeOffline(**kw).eval()
+    fill_synthetic_(std, seed=2)
+    sd = std.state_dict()
+    one_head = CoTrackerThreeOffline(linear_layer_for_vis_conf=False, **kw).eval()
+    sd1 = {k: v for k, v in sd.items() if ".vis_conf_head." not in k}
+    sd1["updateformer.flow_head.weight"] = torch.cat([sd["updateformer.flow_head.weight"], sd["updateformer.vis_conf_head.weight"]])
+    sd1["updateformer.flow_head.bias"] = torch.cat([sd["updateformer.flow_head.bias"], sd["updateformer.vis_conf_head.bias"]])
+    one_head.load_state_dict(sd1, strict=True)
+    no_space = CoTrackerThreeOffline(add_space_attn=False, **kw).eval()
+    no_space.load_state_dict({k: v for k, v in sd.items() if ".space_" not in k}, strict=True)
+    assert not any(".space_" in k for k in no_space.state_dict())
+    std, one_head, no_space = std.to(dev()), one_head.to(dev()), no_space.to(dev())
+    ref = std(video, q, iters=3)
+    assert maxdiff(ref[0], g["off_coords"]) < 1e-2   # (3 iterations here, 4 in the golden: sanity only)
+    out = one_head(video, q, iters=3)
+    assert all(torch.equal(a, b) for a, b in zip(out[:3], ref[:3]))
+    ref_t = std(video, q, iters=3, add_space_attn=False)
+    out_t = no_space(video, q, iters=3)                     # add_space_attn=True at call time, but there is nothing to add
+    assert all(torch.equal(a, b) for a, b in zip(out_t[:3], ref_t[:3]))
+    assert maxdiff(out_t[0], ref[0]) > 1e-3
+    for bad in (dict(corr_radius=2), dict(corr_levels=3), dict(num_virtual_tracks=32)):
+        with pytest.raises(NotImplementedError):
+            CoTrackerThreeOffline(**{**kw, **bad})
 
 
 def test_model_copy_and_pickle_with_pending_stream_state(golden):

@@ -39,8 +39,25 @@ if has lab; then
   (timeout 600 tools/gemm_lab 2>&1 | tail -20) | tee gpurun_out/${R}_gemm_lab.log
 fi
 if has tests; then
-  (timeout 2400 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -60) > gpurun_out/${R}_pytest_gpu.log
-  tail -45 gpurun_out/${R}_pytest_gpu.log
+  timeout 2400 python -m pytest tests -m gpu -q --durations=8 --tb=short > gpurun_out/${R}_pytest_gpu_full.log 2>&1
+  grep -E "^(FAILED|ERROR|E  )|passed|failed" gpurun_out/${R}_pytest_gpu_full.log | head -60
+  (grep -v "^E20\|^W20" gpurun_out/${R}_pytest_gpu_full.log | tail -25) > gpurun_out/${R}_pytest_gpu.log
+fi
+if has retest; then  # the tests named in $CTK_RETEST (a -k expression), full tracebacks
+  timeout 1200 python -m pytest tests -m gpu -q --tb=short -k "$CTK_RETEST" > gpurun_out/${R}_pytest_retest.log 2>&1
+  grep -E "^(FAILED|ERROR|E  )|passed|failed" gpurun_out/${R}_pytest_retest.log | head -80
+fi
+if has convab; then  # encoder: second column phase skipped for the 64-channel layers (default) vs round-3 behaviour
+  for v in 1 0; do
+    (CTK_CONV_PH1=$v timeout 600 python bench.py --workload c2_offline --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/${R}_convab_$v.err | tail -1) > gpurun_out/${R}_bench_c2_convph1_$v.json
+    python - gpurun_out/${R}_bench_c2_convph1_$v.json $v <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print("CTK_CONV_PH1=" + sys.argv[2], d["ms_per_step"], "ms/step; parity", json.dumps(d.get("parity", {}).get("timed_step", {}))[:260])
+for k in d["kernels"]:
+    if k["name"].startswith(("conv_pp128", "enc_")): print("    ", k["name"], k["launches"], k["total_ms"], k["avg_us"])
+PY
+  done
 fi
 if has bench; then
   (timeout 900 python bench.py --steps 5 --warmup 2 2>gpurun_out/${R}_bench_c3.err | tail -1) > gpurun_out/${R}_bench_c3.json
