@@ -82,7 +82,8 @@ int stream_follow(hipStream_t from, hipStream_t to) {
 }
 
 // Knob CTK_OVERLAP (read per call): 0 = ignore aux_stream (everything on the caller's stream), bit 1 = software
-// pipeline sampler || corr_mlp, bit 2 = points<-virtual query projection beside the virtual-track chain.
+// pipeline sampler || corr_mlp, bit 2 = points<-virtual query projection beside the virtual-track chain, bit 4 (round 4) =
+// the time blocks' q projection beside their kv projection (tail filling between two persistent GEMMs).
 // DEFAULT 0: measured on MI355X at C3 (profiles/r02_overlap_and_time_attention_ab.txt) the sampler and the corr_mlp GEMM
 // do NOT complement each other -- run side by side each slows down by more than the other gains (sampler 2.70 -> 4 x
 // 1.21 ms, fc1 2.24 -> 4 x 0.77 ms per iteration; step 1528.5 -> 1547.3 ms) -- and the side query projection is worth
@@ -252,8 +253,15 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     {
       const ctk_block_weights& b = w->time_blocks[i];
       CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, sp, s));
-      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      // to_q and to_kv read the same xn and write disjoint columns of qkv: with an auxiliary stream (CTK_OVERLAP bit 4, opt-in)
+      // the q projection is enqueued beside the kv projection, so that the persistent kv kernel's workgroups take the CUs
+      // the q kernel's last, 1/6-full round leaves idle (a persistent GEMM owns a CU's whole LDS: nothing else can overlap).
+      const bool par_q = fr.aux != nullptr && (overlap_mode() & 4) != 0;
+      JoinGuard qside{s, fr.aux};
+      if (par_q) CTK_TRY(qside.fork());
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, par_q ? fr.aux : s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      if (par_q) CTK_TRY(qside.join());
       CTK_TRY(attn(qkv, QL, S, 1, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, S, 1, att, S, 1, N + CTK_VIRT, S, S, 1, nullptr, s, sp));
       CTK_TRY(gemm(att, CTK_HID, (int)R, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(mlp_block(ws, 0, R, b, s, sp));

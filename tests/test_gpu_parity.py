@@ -792,12 +792,12 @@ def test_constructor_variants_vis_conf_head_and_no_space_blocks(golden):
     no_space.load_state_dict({k: v for k, v in sd.items() if ".space_" not in k}, strict=True)
     assert not any(".space_" in k for k in no_space.state_dict())
     std, one_head, no_space = std.to(dev()), one_head.to(dev()), no_space.to(dev())
-    ref = std(video, q, iters=3)
-    assert maxdiff(ref[0], g["off_coords"]) < 1e-2   # (3 iterations here, 4 in the golden: sanity only)
-    out = one_head(video, q, iters=3)
+    ref = std(video, q, iters=4)
+    assert maxdiff(ref[0], g["off_coords"]) < 1e-3   # the standard model is the one the reference golden pins
+    out = one_head(video, q, iters=4)
     assert all(torch.equal(a, b) for a, b in zip(out[:3], ref[:3]))
-    ref_t = std(video, q, iters=3, add_space_attn=False)
-    out_t = no_space(video, q, iters=3)                     # add_space_attn=True at call time, but there is nothing to add
+    ref_t = std(video, q, iters=4, add_space_attn=False)
+    out_t = no_space(video, q, iters=4)                     # add_space_attn=True at call time, but there is nothing to add
     assert all(torch.equal(a, b) for a, b in zip(out_t[:3], ref_t[:3]))
     assert maxdiff(out_t[0], ref[0]) > 1e-3
     for bad in (dict(corr_radius=2), dict(corr_levels=3), dict(num_virtual_tracks=32)):

@@ -47,6 +47,12 @@ if has retest; then  # the tests named in $CTK_RETEST (a -k expression), full tr
   timeout 1200 python -m pytest tests -m gpu -q --tb=short -k "$CTK_RETEST" > gpurun_out/${R}_pytest_retest.log 2>&1
   grep -E "^(FAILED|ERROR|E  )|passed|failed" gpurun_out/${R}_pytest_retest.log | head -80
 fi
+if has ovab; then  # CTK_OVERLAP bit 4: time-block q projection beside the kv projection (aux stream), A/B/A
+  for v in 0 4 0 4; do
+    (CTK_OVERLAP=$v timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile --no-extra-lines 2>gpurun_out/${R}_ovab_$v.err | tail -1) > gpurun_out/${R}_bench_c3_overlap_$v.json
+    python -c "import json,sys; d=json.load(open('gpurun_out/${R}_bench_c3_overlap_$v.json')); print('CTK_OVERLAP=$v', d['value'], d['ms_per_step'], json.dumps(d['parity']['timed_step'])[-330:-200])"
+  done
+fi
 if has convab; then  # encoder: second column phase skipped for the 64-channel layers (default) vs round-3 behaviour
   for v in 1 0; do
     (CTK_CONV_PH1=$v timeout 600 python bench.py --workload c2_offline --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/${R}_convab_$v.err | tail -1) > gpurun_out/${R}_bench_c2_convph1_$v.json
