@@ -66,7 +66,7 @@ PY
   done
 fi
 if has bench; then
-  (timeout 900 python bench.py --steps 5 --warmup 2 2>gpurun_out/${R}_bench_c3.err | tail -1) > gpurun_out/${R}_bench_c3.json
+  (timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/${R}_bench_c3.err | tail -1) > gpurun_out/${R}_bench_c3.json   # the driver's command
   summ c3 gpurun_out/${R}_bench_c3.json
 fi
 if has more; then
@@ -84,6 +84,11 @@ if has prof; then
   python tools/summarize_rocprof.py /tmp/prof gpurun_out/${R}_rocprof_kernel_stats.txt 2>&1 | tail -3
   tail -5 /tmp/prof_bench.log | cut -c1-300
   head -34 gpurun_out/${R}_rocprof_kernel_stats.txt
+fi
+if has corrpmc; then  # SQ counters of the sampler alone (tools/bench_corr.py micro-benchmark, three separate --pmc passes)
+  bash tools/pmc_corr.sh > gpurun_out/${R}_pmc_corr.txt 2>&1
+  cd $GRAFT_REPO_ROOT
+  grep corr_volume_sh gpurun_out/${R}_pmc_corr.txt | head -30
 fi
 if has sq; then
   cd /tmp && rm -rf /tmp/sq /tmp/ldsc
