@@ -231,7 +231,10 @@ def roofline_mfma(name, rows, traffic, sustained=None):
         out["note"] = "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) peak"
     if len(rows) == 1:
         return _traffic_fields(out, traffic.get(name))
-    trs = [traffic.get(r["name"]) for r in rows]
+    def tr_of(n):  # the PMC file is keyed by KERNEL (tools/pmc_traffic.py): every 64x64-tile shape shares the "gemm_sh_64x64" entry
+        return traffic.get(n) or (traffic.get("gemm_sh_64x64") if n.startswith("gemm_sh_64_") else None)
+
+    trs = [tr_of(r["name"]) for r in rows]
     if all(t and t.get("hbm_bytes_per_launch") for t in trs):  # call-weighted HBM bytes per launch of the class
         tot = sum(t["hbm_bytes_per_launch"] * r["launches"] for t, r in zip(trs, rows))
         agg = {"hbm_bytes_per_launch": tot / n, "source": trs[0].get("source"),

@@ -53,6 +53,22 @@ if has ovab; then  # CTK_OVERLAP bit 4: time-block q projection beside the kv pr
     python -c "import json,sys; d=json.load(open('gpurun_out/${R}_bench_c3_overlap_$v.json')); print('CTK_OVERLAP=$v', d['value'], d['ms_per_step'], json.dumps(d['parity']['timed_step'])[-330:-200])"
   done
 fi
+if has deepab; then  # small-M GEMM kernel: round-3 ring (CTK_GEMM_DEEP64=4) vs 8 slots / 2 K-tiles per iteration (82, default); C4 also with CTK_OVERLAP=2
+  for v in 4 82 4 82; do
+    (CTK_GEMM_DEEP64=$v timeout 600 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra-lines 2>gpurun_out/${R}_deepab_c3_$v.err | tail -1) > gpurun_out/${R}_bench_c3_deep64_$v.json
+    python - gpurun_out/${R}_bench_c3_deep64_$v.json $v <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print("C3 CTK_GEMM_DEEP64=" + sys.argv[2], d["value"], d["ms_per_step"], "gemm_sh_64 rows:", [(k["name"], k["avg_us"]) for k in d["kernels"] if k["name"].startswith("gemm_sh_64")],
+      "parity", d["parity"]["timed_step"]["coords_px"], d["parity"]["timed_step"]["vis_logit"])
+PY
+  done
+  for v in "4 0" "82 0" "82 2" "4 0" "82 0" "82 2"; do
+    set -- $v
+    (CTK_GEMM_DEEP64=$1 CTK_OVERLAP=$2 timeout 600 python bench.py --workload c4_online --steps 24 --warmup 6 --no-cpu-baseline --no-profile 2>gpurun_out/${R}_deepab_c4.err | tail -1) > gpurun_out/${R}_bench_c4_deep64_$1_ov$2.json
+    python -c "import json; d=json.load(open('gpurun_out/${R}_bench_c4_deep64_$1_ov$2.json')); print('C4 DEEP64=$1 OVERLAP=$2', d['value'], d['ms_per_step'])"
+  done
+fi
 if has convab; then  # encoder: second column phase skipped for the 64-channel layers (default) vs round-3 behaviour
   for v in 1 0; do
     (CTK_CONV_PH1=$v timeout 600 python bench.py --workload c2_offline --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/${R}_convab_$v.err | tail -1) > gpurun_out/${R}_bench_c2_convph1_$v.json
