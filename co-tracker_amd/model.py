@@ -279,6 +279,11 @@ class CoTrackerThreeBase(nn.Module):
         # exact-f32 MFMA back end of the same library (fp32 range, as the reference).  range_fallbacks counts hits.
         self.range_guard = True
         self.range_fallbacks = 0
+        # graph streaming only: "deferred" (default) examines a chunk's finiteness flag at the start of the NEXT call, so the
+        # stream of chunk calls never waits for the GPU -- a hit then raises (the chunk was already returned); "immediate" waits
+        # for the flag inside the call (one device-to-host sync per chunk) and, on a hit, restores the online state and re-runs
+        # that chunk on the exact-f32 back end before returning it -- the behaviour of every non-streaming path.
+        self.stream_range_check = "deferred"
         self.encoder_dtype = torch.float32  # fp32 as the reference; see tools/probe_encoder_precision.py for why not lower
         # "hip" (default): the CNN runs on the library's split-half implicit-GEMM convolutions (encoder_hip.py, csrc/conv_pp.hip,
         # csrc/encoder.hip) -- fp32-class accuracy at 2.2x the speed of MIOpen's fp32 convolutions; "torch": nn.Conv2d on
@@ -492,7 +497,7 @@ class CoTrackerThreeOnline(CoTrackerThreeBase):
             assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
         self._hint_now, self._overlap_hint = getattr(self, "_overlap_hint", None), None
         # streaming with the window graph (CoTrackerOnlinePredictor): deferred range check, the chunk stream stays asynchronous
-        deferred = bool(is_online and self.hip_graph and B == 1)
+        deferred = bool(is_online and self.hip_graph and B == 1 and self.stream_range_check == "deferred")
         run = lambda b: self._guarded(  # noqa: E731
             lambda prec: self._forward_one(video[b], queries[b], iters, fmaps_chunk_size, is_online, prec),
             self._online_snapshot() if is_online else None, self._online_restore, deferred)

@@ -66,6 +66,7 @@ class CoTracker2(nn.Module):
         # the flag is examined at the start of the next call and raises -- see _guarded).  range_fallbacks counts hits.
         self.range_guard = True
         self.range_fallbacks = 0
+        self.stream_range_check = "deferred"  # or "immediate" (see CoTrackerThreeBase)
         self._pending_range = None
         # "hip" (default): BasicEncoder on the library's split-half implicit-GEMM convolutions (encoder_hip.py), without the
         # final L2 normalisation CoTracker3 applies; "torch": nn.Conv2d on PyTorch-ROCm / MIOpen (A/B).  Not a reference kwarg.
@@ -220,7 +221,8 @@ def _v2_forward(self, video, queries, iters=4, is_train=False, is_online=False):
         if B != 1:
             raise NotImplementedError("online mode supports B=1")
     self._online_active = bool(is_online)
-    deferred = bool(is_online and self.hip_graph)  # graph streaming: the chunk stream never waits for the GPU
+    # graph streaming: the chunk stream never waits for the GPU (stream_range_check = "immediate": one sync per chunk, transparent re-run)
+    deferred = bool(is_online and self.hip_graph and self.stream_range_check == "deferred")
     snap = (self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted) if is_online else None
 
     def restore(st):

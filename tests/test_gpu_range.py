@@ -188,6 +188,22 @@ def test_overflow_gives_defined_result_not_nan():
     with pytest.raises(FloatingPointError, match="f16 range"):
         m._resolve_deferred_range_check()  # = what predictor.finish() calls
     m._resolve_deferred_range_check()      # nothing pending any more: a no-op
+    # stream_range_check = "immediate": graph streaming that never raises -- the flag is waited for inside the call and the chunk
+    # is re-run on the exact-f32 back end (online state restored first) before it is returned, like every non-streaming path
+    m.stream_range_check = "immediate"
+    exact.hip_graph = True
+    m.init_video_online_processing()
+    exact.init_video_online_processing()
+    before = m.range_fallbacks
+    for ind in range(0, 8, 4):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cs, *_ = m(video[:, ind:ind + 8], q, iters=2, is_online=True)
+        ce, *_ = exact(video[:, ind:ind + 8], q, iters=2, is_online=True)
+        assert torch.equal(cs, ce) and m.online_ind == exact.online_ind
+    assert m.range_fallbacks == before + 2 and m._pending_range is None
+    m.stream_range_check = "deferred"
+    exact.hip_graph = False
     m.hip_graph = False
     # streaming without the graph: immediate check, the online state is restored before the f32 re-run
     m.init_video_online_processing()
