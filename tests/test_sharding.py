@@ -65,6 +65,17 @@ def test_track_sharded_gloo_world2():
             assert out[0] and out[1]
 
 
+def test_track_sharded_gloo_world4_with_short_and_empty_ranks():
+    """ceil(N / world) points per rank: N = 10 on 4 ranks is 3 + 3 + 3 + 1 (a short last chunk, zero-padded in the fixed-size
+    all-gather), N = 3 on 4 ranks leaves rank 3 without a point (it still joins the collective with an empty chunk)."""
+    for n in (10, 3):
+        port = _free_port()
+        with mp.Manager() as mgr:
+            out = mgr.dict()
+            mp.spawn(_worker, args=(4, port, n, out), nprocs=4, join=True)
+            assert all(out[r] for r in range(4)), dict(out)
+
+
 # ---- the same path on the GPU: two gloo ranks sharing cuda:0, a real tracker under track_sharded -----------------
 import pytest  # noqa: E402
 
