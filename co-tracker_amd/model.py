@@ -291,7 +291,8 @@ class CoTrackerThreeBase(nn.Module):
         self.encoder_backend = "hip"
         # streaming: reuse the previous chunk's features for the overlapping frames (see _encode_online).  Not a reference
         # kwarg and OFF by default (the reference re-encodes whatever chunk it is given, predictor.py:288-290); opt in for
-        # streams whose chunks overlap by window_len - step frames (bench.py's configs[3] workload does)
+        # streams whose chunks are overlapping VIEWS of one resident video (see _encode_online: the overlap is proven on the host
+        # by storage aliasing; bench.py --workload c4_online --feature-cache)
         self.online_feature_cache = False
         self.encoder_chunk = 16  # frames per CNN call (see _encode); not a reference kwarg
         # pre-sigmoid (visibility, confidence) of the last forward, [B,T,N] each -- parity tests compare logits
