@@ -40,6 +40,11 @@
 extern "C" {
 #endif
 
+/* ABI history (what a binding written against an older header must know):
+ *   v8 (round 4): + ctk_bilinear_sampler (Op D); ctk_window_args.flags must be 0 or CTK_WINDOW_NO_SPACE_ATTN -- unknown bits are
+ *       CTK_E_SHAPE in every entry point taking the struct; ctk_probe_mfma kind 2; the *_workspace_bytes queries no longer include
+ *       the stream-K scratch (~64 MiB) unless ctk_gemm_pp_mode bit 4 is set when they are called.
+ *   v7: ctk_gemm_scratch_bytes / ctk_gemm_set_scratch.   v6: ctk_window_args.flags, the encoder entry points.   v5: CoTracker2 window. */
 #define CTK_ABI_VERSION 8
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
