@@ -859,6 +859,38 @@ def test_model_online_batched_streaming(golden):
     assert maxdiff(cb[0], g["on_stream_coords"][0]) < 1e-3
 
 
+@pytest.mark.parametrize("case", ["one_point", "short_video", "odd_pyramid", "border_queries", "late_queries_sliding", "offline_odd"])
+def test_model_edge_cases_vs_torch_port(case):
+    """Shapes and inputs the BASELINE configs never produce, HIP model vs oracle/torch_port.py (the reference's ATen CPU ops in the
+    reference's order) with the same weights: a single query point; a video shorter than one window (the reference pads it by
+    repeating the last frame, cotracker3_online.py:321-328); a model resolution whose pyramid has odd sizes (72 x 104 -> 18x26,
+    9x13, 4x6, 2x3: avg_pool floors, 7x7 taps wider than the coarsest map); queries on and outside the image border
+    (border-clamped sampling everywhere); queries entering in later windows with a ragged last window; the offline model on an
+    odd frame count.  The port is pinned on the imported reference FOR EXACTLY THESE INPUTS by
+    tests/test_edge_cases_vs_reference.py (CPU, build container: <= 8.4e-5 px / 8e-6 sigmoid).  Bar: 1e-3 px / 1e-4 logit."""
+    import copy
+    from cotracker_amd.model import CoTrackerThreeOnline, CoTrackerThreeOffline
+    from cotracker_amd.synthetic import synthetic_video
+    from cotracker_amd.weights import fill_synthetic_
+    from oracle import torch_port as TP  # checker only
+    from test_edge_cases_vs_reference import CASES
+    H, W, T, offline, q = CASES[case]
+    q = torch.tensor([q])
+    S = 8
+    cls = CoTrackerThreeOffline if offline else CoTrackerThreeOnline
+    m = cls(stride=4, corr_radius=3, window_len=S, model_resolution=(H, W)).eval()
+    fill_synthetic_(m, seed=7)
+    video = synthetic_video(T, H, W, seed=11)
+    p = {k: v.clone() for k, v in m.state_dict().items() if not k.startswith("fnet.")}
+    rc, rv, rf = TP.model_forward(copy.deepcopy(m.fnet), p, video, q, iters=4, window_len=S, offline=offline)
+    m = m.to(dev())
+    c, v, f, _ = m(video.to(dev()), q.to(dev()), iters=4)
+    vl, fl = m.last_logits
+    assert m.range_fallbacks == 0
+    assert maxdiff(c, rc) < 1e-3, (case, maxdiff(c, rc))
+    assert maxdiff(vl, rv) < 1e-4 and maxdiff(fl, rf) < 1e-4, (case, maxdiff(vl, rv), maxdiff(fl, rf))
+
+
 def test_model_offline(golden):
     from cotracker_amd.model import CoTrackerThreeOffline
     from cotracker_amd.weights import fill_synthetic_
