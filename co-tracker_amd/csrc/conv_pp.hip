@@ -223,6 +223,186 @@ __global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_t
   }
 }
 
+// ================================================================================================================
+// Round 4: 3 x 3 / stride 1 / pad 1 convolutions with the input tile held in LDS ("halo" kernel).
+//
+// conv_pp128_kernel fetches a K-tile's A operand -- one 128-byte line per output pixel and (tap, channel group) -- by
+// LDS-DMA for EVERY tap: nine fetches of (almost) the same input lines, 48 KiB of DMA per K-tile and workgroup.  Measured
+// (profiles/r04_overlap_qkv_ab.txt and the per-launch rows of bench.py): 1.65 us per K-tile whatever the MFMA work (halving
+// the MFMAs of the 64-channel layers bought 7 %) = 29 GB/s per CU, the rate one CU's LDS-DMA request stream sustains
+// (MI355X_MICROARCH.md "ldsdma-fill": 25 GB/s per CU) -- the 3 x 3 layers are bound by that stream, not by the matrix pipe.
+// Here a workgroup owns 8 x 32 output pixels (256 GEMM rows) x 128 output channels and fetches, per 32-channel group, the
+// 10 x 34-pixel input halo ONCE (340 lines, 42.5 KiB); the nine taps read their A fragments from that halo at shifted
+// rows.  DMA per K-tile: the weights' 16 KiB (8 KiB when only 64 output columns are stored) + 1/9 of a halo = 21 (13) KiB
+// instead of 48.
+//   LDS: halo[2] (double-buffered over channel groups, 48 KiB each: 384 rows of 128 B, XOR-swizzled by the PHYSICAL halo
+//        row exactly like the GEMM's A rows, so a fragment read of 32 consecutive pixels of an output row is conflict-free
+//        at any tap offset) | weight ring 3 x 16 KiB | bias; the epilogue's transpose scratch aliases halo[0].
+//   K order: channel group outer, tap inner (the packed weights stay [n][ky][kx][c]: only the K-tile index is remapped).
+//   Schedule (all 8 waves in the same phase, ONE barrier per K-tile, every wave issues the same number of pieces so the
+//   counted vmcnt waits are uniform): iteration kt = (cg, tap):
+//       wait  vmcnt(NB + (tap == 1 ? 6 : 0))   -> my pieces of B(kt) (and of halo(cg) at tap 0) have landed
+//       barrier                                  -> everyone's have; everyone is done reading B(kt-1) and, at tap 0, halo(cg-1)
+//       issue [tap == 0: halo(cg+1) -> halo[(cg+1)&1], 6 pieces per wave], B(kt+2) -> ring slot (kt+2) % 3, NB pieces per wave
+//       read A fragments (halo[cg&1] at the tap's row offset), B fragments; MFMAs
+//   (requests beyond the last K-tile / channel group are duplicates of the last one into free slots, drained at tile end).
+// Same products, same f32 accumulation per output as conv_pp128_kernel up to the ORDER of the K-tiles (channel group outer
+// instead of tap outer): results agree to f32 rounding, not bit for bit; per-frame determinism is unchanged (a tile never
+// straddles frames).  Requires Hout % 8 == 0 and Wout % 32 == 0 (every layer of the 384 x 512 model resolution); other
+// shapes and the stride-2 / 1 x 1 convolutions stay on conv_pp128_kernel.
+constexpr int CH_HALO = 49152;             // one halo buffer: 48 pieces of 1 KiB (rows 340..383 are never read)
+constexpr int CH_B0 = 2 * CH_HALO;         // weight ring
+constexpr int CH_BSLOT = 16384;
+constexpr int CH_BIAS = CH_B0 + 3 * CH_BSLOT;  // 147456
+static_assert(CH_BIAS + 4096 <= PP_LDS_ALL, "LDS budget");
+
+template <int EPI, bool N64>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles_total) {
+  constexpr bool DBG = false;
+  constexpr int NB = N64 ? 1 : 2;  // weight pieces per wave and K-tile (8 or 16 pieces of 8 rows)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS_ALL];
+  const CtkGemmP& g = p.g;
+  const int dbg = 0;
+  unsigned jctr = 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+  const unsigned l3 = lane >> 3, l4 = lane >> 4, l7 = lane & 7;
+  const int cl = p.CL, KT = 9 * cl;
+  const float w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
+  const float* bias_lds = reinterpret_cast<const float*>(lds + CH_BIAS);
+  if ((EPI & 32) != 0) {
+    for (int i = tid; i < g.N / 4; i += 512) reinterpret_cast<f32x4*>(lds + CH_BIAS)[i] = reinterpret_cast<const f32x4*>(g.bias)[i];
+    __syncthreads();
+  }
+  const unsigned char* in = static_cast<const unsigned char*>(g.A);
+  const unsigned char* wsh = reinterpret_cast<const unsigned char*>(g.Wp) + PP_HDR_BYTES;
+  const unsigned ldw_b = (unsigned)KT * 128;
+  const int ty_tiles = p.Hout / 8, tx_tiles = p.Wout / 32;
+  auto cbyte = [&](const int piece) { return ((l7 ^ ((4 * piece + l4) & 7)) << 4); };
+
+  // fragment addressing inside a halo buffer / a weight slot: [j][plane] chunk positions depend on the PHYSICAL row's swizzle
+  // A row of lane (mi): halo row R = (wm*2 + mi + ky) * 34 + r32 + kx  ->  byte R*128 + ((chunk ^ ((R >> 1) & 7)) << 4)
+  const int fswb = (r32 >> 1) & 7;
+  unsigned b_rd0[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) b_rd0[j][pl] = (unsigned)((wn * 32 + r32) * 128 + (((pl * 4 + j * 2 + half) ^ fswb) << 4));
+
+  f32x16 acc[2][2];
+  f16x8 fa[2][2][2], fb[2][2];
+
+  for (int q = 0;; ++q) {  // my tiles
+    const int G = gridDim.x, first = q * G;
+    if (first >= tiles_total) break;
+    const int n_r = min(G, tiles_total - first);
+    if ((int)blockIdx.x >= n_r) break;
+    unsigned tile = first + ctk_xcd_remap(blockIdx.x, n_r);
+    const int nb = tile % g.nblocks;
+    tile /= g.nblocks;
+    const int tx = tile % tx_tiles;
+    tile /= tx_tiles;
+    const int ty = tile % ty_tiles;
+    const int f = tile / ty_tiles;
+    const int n0 = nb * 128, y0 = ty * 8, x0 = tx * 32;
+
+    // ---- per-lane halo sources of my 6 pieces (pieces 6w .. 6w+5; halo row r = 8 piece + l3 = hy*34 + hx)
+    long hsrc[6];  // byte offset of the pixel's first line in `in`, or -1: zero line (padding ring / rows >= 340)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int r = 8 * (6 * wave + e) + (int)l3;
+      const int hy = r / 34, hx = r - hy * 34;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = r < 340 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      hsrc[e] = ok ? ((long)(f * p.Hin + iy) * p.Win + ix) * cl * 128 : -1;
+    }
+    auto issue_halo = [&](int cg, const int buf) {  // 6 pieces per wave
+      cg = min(cg, cl - 1);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int piece = 6 * wave + e;
+        const unsigned char* src = (hsrc[e] >= 0 ? in + hsrc[e] + (long)cg * 128 : p.zeros) + cbyte(piece);
+        __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + buf * CH_HALO + piece * 1024), 16, 0, 0);
+      }
+    };
+    auto issue_b = [&](int kt, const int slot) {  // K-tile kt = cg * 9 + tap  ->  packed K-tile tap * cl + cg; NB pieces per wave
+      kt = min(kt, KT - 1);
+      const int cg = kt / 9, tap = kt - cg * 9;
+      const long koff = (long)(tap * cl + cg) * 128;
+#pragma unroll
+      for (int e = 0; e < NB; ++e) {
+        const int piece = NB * wave + e;  // W rows n0 + 8 piece + l3
+        const unsigned char* src = wsh + (long)(n0 + 8 * piece + (int)l3) * ldw_b + koff + cbyte(piece);
+        __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + CH_B0 + slot * CH_BSLOT + piece * 1024), 16, 0, 0);
+      }
+    };
+
+    issue_halo(0, 0);
+    issue_b(0, 0);
+    issue_b(1, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    int slot = 0, kt = 0;
+    for (int cg = 0; cg < cl; ++cg) {
+      const unsigned hb = (cg & 1) * CH_HALO;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap, ++kt) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        if (tap == 1) PP_WAIT_VM(NB + 6);
+        else PP_WAIT_VM(NB);
+        PP_BARRIER();
+        if (tap == 0) issue_halo(cg + 1, (cg + 1) & 1);
+        issue_b(kt + 2, slot == 0 ? 2 : slot - 1);
+        const unsigned so = CH_B0 + slot * CH_BSLOT;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const unsigned R = (unsigned)((wm * 2 + mi + ky) * 34 + r32 + kx);
+          const unsigned base = hb + R * 128, sw = (R >> 1) & 7;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa[mi][j][pl] = *reinterpret_cast<const f16x8*>(lds + base + ((((unsigned)(pl * 4 + j * 2 + half)) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int n = 0; n < (N64 ? 1 : 2); ++n) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl] + n * 8192);
+          PP_WAIT_LGKM0();
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+                acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][n], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+    }
+    // ---- tile end: drain the duplicate tail requests; halo[0] becomes the transpose scratch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    {
+      const int prow = (f * p.Hout + y0 + wm * 2) * p.Wout + x0;  // linear output pixel of (f, y0 + wm*2 + mi, x0): 32 consecutive pixels per mi
+      const int ncol = n0 + wn * 32;
+      pp_epilogue<EPI, 2, 2>(g, acc, lane, 0, w_unscale, bias_lds, lds + wave * 4096, [&](int mi) { return prow + mi * p.Wout; },
+                             [&](int ni) { return ncol + ni * 64; }, false, p.n_valid);
+    }
+    PP_BARRIER();  // scratch reads done before the next tile's halo lands
+  }
+}
+
 }  // namespace
 
 // in_sh: SH activations NHWC [F][Hin][Win][Cin/32] lines; wp: ctk_pack_weight of the [Npad][KH*KW*Cin] matrix ([n][ky][kx][c] order,
@@ -262,6 +442,20 @@ extern "C" int ctk_conv2d_sh(const void* in_sh, int32_t F, int32_t Hin, int32_t 
   char pname[48];
   snprintf(pname, sizeof(pname), "conv_pp128_%dx%d_s%d_c%d_n%d", KH, KW, stride, Cin, n_out);
   const double flops = 2.0 * M * (double)n_out * g.K;
+  // 3 x 3 / stride 1 / pad 1 on tile-aligned maps: the halo kernel (input tile in LDS, nine taps read it there).  CTK_CONV_HALO=0
+  // (dev A/B knob, read once) keeps every convolution on conv_pp128_kernel.
+  static const bool halo_on = [] { const char* e = getenv("CTK_CONV_HALO"); return !(e && atoi(e) == 0); }();
+  if (halo_on && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Hout % 8 == 0 && Wout % 32 == 0 && Hout == Hin && Wout == Win) {
+    const long htiles = (long)F * (Hout / 8) * (Wout / 32) * g.nblocks;
+    char hname[48];
+    snprintf(hname, sizeof(hname), "conv_halo_3x3_c%d_n%d", Cin, n_out);
+    CtkProfScope hps(hname, flops, 4.0 * ((double)F * Hin * Win * Cin + (double)M * n_out), s);
+    const dim3 hgrid((unsigned)(htiles < cus ? htiles : cus));
+    if (n_out <= 64) hipLaunchKernelGGL((conv3x3_halo_kernel<32, true>), hgrid, dim3(512), 0, s, p, (int)htiles);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<32, false>), hgrid, dim3(512), 0, s, p, (int)htiles);
+    CTK_HIP_CHECK_LAUNCH();
+    return CTK_OK;
+  }
   CtkProfScope ps(pname, flops, 4.0 * ((double)F * Hin * Win * Cin + (double)M * n_out), s);
   static const bool force_ph1 = [] { const char* e = getenv("CTK_CONV_PH1"); return e && atoi(e) == 1; }();  // dev A/B knob (read once): 1 = round-3 behaviour
   hipLaunchKernelGGL((conv_pp128_kernel<32>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p, (int)tiles, force_ph1);

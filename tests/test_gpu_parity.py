@@ -568,6 +568,45 @@ def test_sample_features_4d_5d_match_reference_semantics(golden):
     assert torch.equal(sample_features5d(vid.to(dev()), c5.to(dev())).cpu(), ref5)
 
 
+@pytest.mark.parametrize("shape", [  # (F, H, W, Cin, Cout, k, stride): halo kernel <=> 3x3 / stride 1 / H % 8 == 0 / W % 32 == 0
+    (2, 16, 64, 64, 64, 3, 1),      # halo, 64 output columns (one column phase, 8 KiB of weights per K-tile)
+    (1, 24, 32, 96, 96, 3, 1),      # halo, 96 of 128 columns stored, three channel groups (odd: the double buffer ends on buffer 0)
+    (2, 8, 96, 128, 128, 3, 1),     # halo, full 128 columns, three tiles per row, one tile row: the padding ring on every side
+    (1, 16, 32, 160, 256, 3, 1),    # halo, two column blocks (conv2's shape class)
+    (2, 12, 40, 64, 64, 3, 1),      # NOT tile-aligned -> conv_pp128_kernel
+    (2, 16, 64, 64, 96, 3, 2),      # stride 2 -> conv_pp128_kernel
+    (1, 16, 64, 128, 128, 1, 1),    # 1 x 1 -> conv_pp128_kernel
+])
+def test_conv2d_sh_vs_fp64(shape):
+    """ctk_conv2d_sh (the encoder's convolutions: conv3x3_halo_kernel where it applies, conv_pp128_kernel elsewhere) against
+    torch's conv2d in float64 on the CPU: random NHWC activations in SH form, random weights and bias.  Split-half products
+    carry ~2^-21 relative error each; the bound is on |out - ref| relative to the output scale."""
+    from cotracker_amd import ops
+    from cotracker_amd.encoder_hip import HipEncoder, _Conv
+    F, H, W, Cin, Cout, k, stride = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=k // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (Cin * k * k) ** 0.5)
+        conv.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+    x = torch.randn(F, Cin, H, W, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=stride, padding=k // 2)
+    enc = HipEncoder.__new__(HipEncoder)   # only the primitives: device, zeros
+    enc.device, enc.zeros = dev(), torch.zeros(64, device=dev())
+    cv = _Conv(conv, dev())
+    x_sh = ops.split_rows(x.permute(0, 2, 3, 1).reshape(F * H * W, Cin).contiguous().to(dev()))
+    out, Ho, Wo = enc._conv(x_sh, F, H, W, cv)
+    out = out.view(F, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert out.shape == ref.shape
+    err = maxdiff(out, ref)
+    assert err <= 4e-6 * max(1.0, float(ref.abs().max())), (shape, err, float(ref.abs().max()))
+    # determinism, and frame independence: frame 0 alone gives the bits it has inside the batch
+    out2, _, _ = enc._conv(x_sh, F, H, W, cv)
+    assert torch.equal(out2.view(F, Ho, Wo, Cout).permute(0, 3, 1, 2), out)
+    one, _, _ = enc._conv(x_sh[: H * W].contiguous(), 1, H, W, cv)
+    assert torch.equal(one.view(1, Ho, Wo, Cout).permute(0, 3, 1, 2)[0], out[0])
+
+
 @pytest.mark.parametrize("which", ["online", "offline", "cotracker2"])
 def test_encoder_hip_vs_reference_fnet(golden, which):
     """SURVEY 8f-4, stage level: BasicEncoder.forward (blocks.py:141-219) on the HIP implicit-GEMM convolutions against the
@@ -602,6 +641,28 @@ def test_encoder_hip_vs_reference_fnet(golden, which):
     one = torch.cat([enc(video[i:i + 1].float().contiguous()) for i in (3, 0)])
     assert torch.equal(one[0], nrm[3]) and torch.equal(one[1], nrm[0])
     assert torch.equal(enc(video[2:7].float().contiguous()), nrm[2:7])
+
+
+def test_encoder_hip_at_model_resolution_vs_torch_cpu():
+    """BasicEncoder at the real 384 x 512 model resolution, where every 3 x 3 / stride-1 layer runs on the halo kernel (the toy
+    resolutions of the goldens are not tile-aligned and stay on conv_pp128_kernel): HIP vs the same module's torch forward on
+    the CPU in fp32 (the ops the reference calls), two frames; raw features <= 5e-6 of the feature scale, and each frame alone
+    gives the bits it has in the batch."""
+    from cotracker_amd.encoder_hip import HipEncoder
+    from cotracker_amd.model import CoTrackerThreeOnline
+    from cotracker_amd.synthetic import synthetic_video
+    from cotracker_amd.weights import fill_synthetic_
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=16).eval()
+    fill_synthetic_(m, seed=3)
+    video = synthetic_video(2, 384, 512, seed=9)[0]
+    with torch.no_grad():
+        ref = m.fnet(2 * (video / 255.0) - 1.0).permute(0, 2, 3, 1).contiguous()
+    m = m.to(dev())
+    enc = HipEncoder(m.fnet, dev(), normalize=False)
+    out = enc(video.to(dev()).float().contiguous())
+    scale = float(ref.abs().max())
+    assert maxdiff(out, ref) <= 5e-6 * max(1.0, scale), (maxdiff(out, ref), scale)
+    assert torch.equal(enc(video[1:2].to(dev()).float().contiguous())[0], out[1])
 
 
 def test_model_online_sliding_and_streaming(golden):
