@@ -241,11 +241,13 @@ __global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_t
 //   K order: channel group outer, tap inner (the packed weights stay [n][ky][kx][c]: only the K-tile index is remapped).
 //   Schedule (all 8 waves in the same phase, ONE barrier per K-tile, every wave issues the same number of pieces so the
 //   counted vmcnt waits are uniform): iteration kt = (cg, tap):
-//       wait  vmcnt(NB + (tap == 1 ? 6 : 0))   -> my pieces of B(kt) (and of halo(cg) at tap 0) have landed
-//       barrier                                  -> everyone's have; everyone is done reading B(kt-1) and, at tap 0, halo(cg-1)
-//       issue [tap == 0: halo(cg+1) -> halo[(cg+1)&1], 6 pieces per wave], B(kt+2) -> ring slot (kt+2) % 3, NB pieces per wave
-//       read A fragments (halo[cg&1] at the tap's row offset), B fragments; MFMAs
+//       wait  vmcnt(NB + (1 <= tap <= 6 ? 1 : 0)) -> my pieces of B(kt) have landed (and everything older: my halo pieces)
+//       barrier                                     -> everyone's have; everyone is done reading B(kt-1) and, at tap 0, halo(cg-1)
+//       read B(kt) fragments, then the A fragments of K-tile kt+1 (one K-tile ahead: the halo is resident); MFMAs of kt
+//       issue [taps 0..5: ONE piece per wave of halo(cg+1) -> halo[(cg+1)&1]], B(kt+2) -> ring slot (kt+2) % 3, NB pieces per wave
 //   (requests beyond the last K-tile / channel group are duplicates of the last one into free slots, drained at tile end).
+//   First version (all DMA issued in front of the fragment reads, halo in one burst at tap 0, A fragments read in the K-tile that
+//   uses them): 208 us on the 64-channel layer against 372 for conv_pp128_kernel; see profiles/r04_conv_halo_ab.txt.
 // Same products, same f32 accumulation per output as conv_pp128_kernel up to the ORDER of the K-tiles (channel group outer
 // instead of tap outer): results agree to f32 rounding, not bit for bit; per-frame determinism is unchanged (a tile never
 // straddles frames).  Requires Hout % 8 == 0 and Wout % 32 == 0 (every layer of the 384 x 512 model resolution); other
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
     for (int pl = 0; pl < 2; ++pl) b_rd0[j][pl] = (unsigned)((wn * 32 + r32) * 128 + (((pl * 4 + j * 2 + half) ^ fswb) << 4));
 
   f32x16 acc[2][2];
-  f16x8 fa[2][2][2], fb[2][2];
+  f16x8 fb[2][2];
 
   for (int q = 0;; ++q) {  // my tiles
     const int G = gridDim.x, first = q * G;
@@ -327,6 +329,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
         __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + buf * CH_HALO + piece * 1024), 16, 0, 0);
       }
     };
+    auto issue_halo_piece = [&](int cg, const int buf, const int e) {  // piece 6 wave + e (e: compile-time)
+      cg = min(cg, cl - 1);
+      const int piece = 6 * wave + e;
+      const unsigned char* src = (hsrc[e] >= 0 ? in + hsrc[e] + (long)cg * 128 : p.zeros) + cbyte(piece);
+      __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + buf * CH_HALO + piece * 1024), 16, 0, 0);
+    };
     auto issue_b = [&](int kt, const int slot) {  // K-tile kt = cg * 9 + tap  ->  packed K-tile tap * cl + cg; NB pieces per wave
       kt = min(kt, KT - 1);
       const int cg = kt / 9, tap = kt - cg * 9;
@@ -349,34 +357,54 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // A fragments of K-tile (cg, tap) -> fa2[tap & 1]: the halo is resident, so they are read one K-tile AHEAD, behind the weight
+    // fragments of the current K-tile and in front of its MFMAs (the LDS serves a wave in order: the MFMAs wait for the weight
+    // fragments only).  Nine taps per channel group is odd, so the fragments prefetched at tap 8 land in buffer 1 and move to
+    // buffer 0 once per channel group.
+    f16x8 fa2[2][2][2][2];  // [buffer][mi][j][plane]
+    auto read_a = [&](const int buf, const unsigned hbase, const int ky, const int kx) {
+      unsigned xl = (unsigned)r32;
+      asm volatile("" : "+v"(xl));  // opaque per call: otherwise hipcc hoists the swizzled addresses of all nine taps out of the
+                                    // channel-group loop (72 VGPRs of loop invariants -> 256 registers and scratch spills)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const unsigned R = (unsigned)((wm * 2 + mi + ky) * 34 + kx) + xl;
+        const unsigned base = hbase + R * 128, sw = (R >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa2[buf][mi][j][pl] = *reinterpret_cast<const f16x8*>(lds + base + ((((unsigned)(pl * 4 + j * 2 + half)) ^ sw) << 4));
+      }
+    };
+
     int slot = 0, kt = 0;
     for (int cg = 0; cg < cl; ++cg) {
       const unsigned hb = (cg & 1) * CH_HALO;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap, ++kt) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        if (tap == 1) PP_WAIT_VM(NB + 6);
+        // my pieces of B(kt) have landed: the requests younger than them are B(kt+1) and, when the previous iteration issued
+        // one, a piece of halo(cg+1) (issued at taps 0..5 of a channel group, one per tap)
+        if (tap >= 1 && tap <= 6) PP_WAIT_VM(NB + 1);
         else PP_WAIT_VM(NB);
         PP_BARRIER();
-        if (tap == 0) issue_halo(cg + 1, (cg + 1) & 1);
-        issue_b(kt + 2, slot == 0 ? 2 : slot - 1);
         const unsigned so = CH_B0 + slot * CH_BSLOT;
+        if (kt == 0) read_a(0, hb, 0, 0);  // first K-tile of the tile: nothing was prefetched
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const unsigned R = (unsigned)((wm * 2 + mi + ky) * 34 + r32 + kx);
-          const unsigned base = hb + R * 128, sw = (R >> 1) & 7;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fa[mi][j][pl] = *reinterpret_cast<const f16x8*>(lds + base + ((((unsigned)(pl * 4 + j * 2 + half)) ^ sw) << 4));
-        }
+          for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl]);
+        // next K-tile's A fragments: same channel group, or (tap 8) the next group's halo -- complete since every wave's wait
+        // above covered its halo pieces (they are older than B(kt)) and the barrier made that global
+        if (tap < 8) read_a((tap + 1) & 1, hb, (tap + 1) / 3, (tap + 1) % 3);
+        else if (cg + 1 < cl) read_a(1, hb ^ CH_HALO, 0, 0);
 #pragma unroll
         for (int n = 0; n < (N64 ? 1 : 2); ++n) {
+          if (n == 1) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl] + n * 8192);
-          PP_WAIT_LGKM0();
+              for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl] + 8192);
+          }
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int j = 0; j < 2; ++j)
@@ -384,10 +412,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
             for (int term = 0; term < 3; ++term)
 #pragma unroll
               for (int mi = 0; mi < 2; ++mi)
-                acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][n], 0, 0, 0);
+                acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa2[tap & 1][mi][j][term == 1 ? 1 : 0], acc[mi][n], 0, 0, 0);
           __builtin_amdgcn_s_setprio(0);
         }
+        // DMA requests behind the MFMAs (an LDS-DMA piece costs ~60 issue cycles among running MFMAs, 100-185 in front of them):
+        // one piece of the next channel group's halo per tap (taps 0..5), the weights two K-tiles ahead
+        if (tap < 6) issue_halo_piece(cg + 1, (cg + 1) & 1, tap);
+        issue_b(kt + 2, slot == 0 ? 2 : slot - 1);
         slot = slot == 2 ? 0 : slot + 1;
+      }
+      if (cg + 1 < cl) {  // tap 8 prefetched into buffer 1; tap 0 of the next group reads buffer 0
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa2[0][mi][j][pl] = fa2[1][mi][j][pl];
       }
     }
     // ---- tile end: drain the duplicate tail requests; halo[0] becomes the transpose scratch
