@@ -252,16 +252,48 @@ __global__ __launch_bounds__(512) void conv_pp128_kernel(CtkConvP p, int tiles_t
 // instead of tap outer): results agree to f32 rounding, not bit for bit; per-frame determinism is unchanged (a tile never
 // straddles frames).  Requires Hout % 8 == 0 and Wout % 32 == 0 (every layer of the 384 x 512 model resolution); other
 // shapes and the stride-2 / 1 x 1 convolutions stay on conv_pp128_kernel.
-constexpr int CH_HALO = 49152;             // one halo buffer: 48 pieces of 1 KiB (rows 340..383 are never read)
-constexpr int CH_B0 = 2 * CH_HALO;         // weight ring
-constexpr int CH_BSLOT = 16384;
-constexpr int CH_BIAS = CH_B0 + 3 * CH_BSLOT;  // 147456
-static_assert(CH_BIAS + 4096 <= PP_LDS_ALL, "LDS budget");
+constexpr int CH_PIECES = 43;                   // 340 halo rows = 42.5 pieces of 8 rows: waves 0..2 fetch 6 pieces, waves 3..7 five
+constexpr int CH_HALO = CH_PIECES * 1024;       // one halo buffer (44 032 B)
+constexpr int CH_B0 = 2 * CH_HALO;              // weight ring: 64 KiB = 8 units of 8 KiB (64 weight rows of one K-tile)
+constexpr int CH_BRING = 65536;
+constexpr int CH_BIAS = CH_B0 + CH_BRING;       // 153 600
+static_assert(CH_BIAS + 4096 <= PP_LDS_ALL && (CH_B0 % 1024) == 0, "LDS budget");
+
+// halo pieces a wave issued in the D - 1 iterations before K-tile (cg, tap): they are YOUNGER than its weight pieces B(kt)
+// (issued D iterations ago), so the counted wait for B(kt) must let them stay in flight.  One piece per tap at taps < nh;
+// `first`: channel group 0, where iterations before tap 0 do not exist.
+constexpr int ch_halo_young(const int tap, const int D, const int nh, const bool first) {
+  int c = 0;
+  for (int i = 1; i < D; ++i) {
+    int t = tap - i;
+    if (first) {
+      if (t < 0) continue;
+    } else {
+      t = ((t % 9) + 9) % 9;
+    }
+    if (t < nh) ++c;
+  }
+  return c;
+}
+
+template <bool DBG>
+__device__ __forceinline__ void ch_wait_vm(const int n) {  // wave-uniform n in 0 .. 15 -> s_waitcnt vmcnt(n)
+  switch (n) {
+#define CH_CASE(N) case N: PP_WAIT_VM(N); break;
+    CH_CASE(0) CH_CASE(1) CH_CASE(2) CH_CASE(3) CH_CASE(4) CH_CASE(5) CH_CASE(6) CH_CASE(7)
+    CH_CASE(8) CH_CASE(9) CH_CASE(10) CH_CASE(11) CH_CASE(12) CH_CASE(13) CH_CASE(14) CH_CASE(15)
+#undef CH_CASE
+    default: PP_WAIT_VM(0); break;
+  }
+}
 
 template <int EPI, bool N64>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles_total) {
   constexpr bool DBG = false;
-  constexpr int NB = N64 ? 1 : 2;  // weight pieces per wave and K-tile (8 or 16 pieces of 8 rows)
+  constexpr int NB = N64 ? 1 : 2;            // weight pieces per wave and K-tile (8 or 16 pieces of 8 rows)
+  constexpr int BSLOT = N64 ? 8192 : 16384;  // bytes of one K-tile's weights
+  constexpr int RING = CH_BRING / BSLOT;     // 8 or 4 K-tiles
+  constexpr int D = RING - 1;                // weights are requested D K-tiles ahead
   __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS_ALL];
   const CtkGemmP& g = p.g;
   const int dbg = 0;
@@ -272,6 +304,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
   const int r32 = lane & 31, half = lane >> 5;
   const unsigned l3 = lane >> 3, l4 = lane >> 4, l7 = lane & 7;
   const int cl = p.CL, KT = 9 * cl;
+  const bool six = wave < 3;                               // my halo piece count: 6 (waves 0..2) or 5
+  const int piece0 = six ? 6 * wave : 18 + 5 * (wave - 3);  // my first halo piece
   const float w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
   const float* bias_lds = reinterpret_cast<const float*>(lds + CH_BIAS);
   if ((EPI & 32) != 0) {
@@ -284,8 +318,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
   const int ty_tiles = p.Hout / 8, tx_tiles = p.Wout / 32;
   auto cbyte = [&](const int piece) { return ((l7 ^ ((4 * piece + l4) & 7)) << 4); };
 
-  // fragment addressing inside a halo buffer / a weight slot: [j][plane] chunk positions depend on the PHYSICAL row's swizzle
-  // A row of lane (mi): halo row R = (wm*2 + mi + ky) * 34 + r32 + kx  ->  byte R*128 + ((chunk ^ ((R >> 1) & 7)) << 4)
   const int fswb = (r32 >> 1) & 7;
   unsigned b_rd0[2][2];
 #pragma unroll
@@ -310,28 +342,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
     const int f = tile / ty_tiles;
     const int n0 = nb * 128, y0 = ty * 8, x0 = tx * 32;
 
-    // ---- per-lane halo sources of my 6 pieces (pieces 6w .. 6w+5; halo row r = 8 piece + l3 = hy*34 + hx)
+    // ---- per-lane halo sources of my pieces (halo row r = 8 piece + l3 = hy*34 + hx)
     long hsrc[6];  // byte offset of the pixel's first line in `in`, or -1: zero line (padding ring / rows >= 340)
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
-      const int r = 8 * (6 * wave + e) + (int)l3;
+      const int r = 8 * (piece0 + e) + (int)l3;
       const int hy = r / 34, hx = r - hy * 34;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
       const bool ok = r < 340 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
       hsrc[e] = ok ? ((long)(f * p.Hin + iy) * p.Win + ix) * cl * 128 : -1;
     }
-    auto issue_halo = [&](int cg, const int buf) {  // 6 pieces per wave
+    auto issue_halo_piece = [&](int cg, const int buf, const int e) {  // my e-th piece (e: compile-time; e = 5 only for waves 0..2)
       cg = min(cg, cl - 1);
-#pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        const int piece = 6 * wave + e;
-        const unsigned char* src = (hsrc[e] >= 0 ? in + hsrc[e] + (long)cg * 128 : p.zeros) + cbyte(piece);
-        __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + buf * CH_HALO + piece * 1024), 16, 0, 0);
-      }
-    };
-    auto issue_halo_piece = [&](int cg, const int buf, const int e) {  // piece 6 wave + e (e: compile-time)
-      cg = min(cg, cl - 1);
-      const int piece = 6 * wave + e;
+      const int piece = piece0 + e;
       const unsigned char* src = (hsrc[e] >= 0 ? in + hsrc[e] + (long)cg * 128 : p.zeros) + cbyte(piece);
       __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + buf * CH_HALO + piece * 1024), 16, 0, 0);
     };
@@ -343,13 +366,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
       for (int e = 0; e < NB; ++e) {
         const int piece = NB * wave + e;  // W rows n0 + 8 piece + l3
         const unsigned char* src = wsh + (long)(n0 + 8 * piece + (int)l3) * ldw_b + koff + cbyte(piece);
-        __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + CH_B0 + slot * CH_BSLOT + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + CH_B0 + slot * BSLOT + piece * 1024), 16, 0, 0);
       }
     };
 
-    issue_halo(0, 0);
-    issue_b(0, 0);
-    issue_b(1, 1);
+    // ---- prologue: the first channel group's halo, the weights of K-tiles 0 .. D-1
+#pragma unroll
+    for (int e = 0; e < 5; ++e) issue_halo_piece(0, 0, e);
+    if (six) issue_halo_piece(0, 0, 5);
+#pragma unroll
+    for (int i = 0; i < D; ++i) issue_b(i, i);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -382,19 +408,27 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
       const unsigned hb = (cg & 1) * CH_HALO;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap, ++kt) {
-        // my pieces of B(kt) have landed: the requests younger than them are B(kt+1) and, when the previous iteration issued
-        // one, a piece of halo(cg+1) (issued at taps 0..5 of a channel group, one per tap)
-        if (tap >= 1 && tap <= 6) PP_WAIT_VM(NB + 1);
-        else PP_WAIT_VM(NB);
+        // my pieces of B(kt) have landed when at most the requests YOUNGER than them are in flight: the weights of K-tiles
+        // kt+1 .. kt+D-1 and the halo pieces of the last D-1 iterations
+        {
+          constexpr int base = (D - 1) * NB;
+          const int young = cg == 0 ? (six ? ch_halo_young(tap, D, 6, true) : ch_halo_young(tap, D, 5, true))
+                                    : (six ? ch_halo_young(tap, D, 6, false) : ch_halo_young(tap, D, 5, false));
+          int allow = base + young;
+          // tap 8 also reads the NEXT channel group's halo (the A prefetch below): all of it must have landed, i.e. only the
+          // weight pieces issued at or after the iteration of my last halo piece (tap 5 / tap 4) may still be in flight
+          if (tap == 8) allow = min(allow, NB * (six ? 3 : 4));
+          ch_wait_vm<DBG>(allow);
+        }
         PP_BARRIER();
-        const unsigned so = CH_B0 + slot * CH_BSLOT;
+        const unsigned so = CH_B0 + slot * BSLOT;
         if (kt == 0) read_a(0, hb, 0, 0);  // first K-tile of the tile: nothing was prefetched
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl]);
-        // next K-tile's A fragments: same channel group, or (tap 8) the next group's halo -- complete since every wave's wait
-        // above covered its halo pieces (they are older than B(kt)) and the barrier made that global
+        // next K-tile's A fragments: same channel group, or (tap 8) the next group's halo -- complete: the stricter wait of tap 8
+        // covered every wave's own halo pieces and the barrier made that global
         if (tap < 8) read_a((tap + 1) & 1, hb, (tap + 1) / 3, (tap + 1) % 3);
         else if (cg + 1 < cl) read_a(1, hb ^ CH_HALO, 0, 0);
 #pragma unroll
@@ -415,11 +449,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
                 acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa2[tap & 1][mi][j][term == 1 ? 1 : 0], acc[mi][n], 0, 0, 0);
           __builtin_amdgcn_s_setprio(0);
         }
-        // DMA requests behind the MFMAs (an LDS-DMA piece costs ~60 issue cycles among running MFMAs, 100-185 in front of them):
-        // one piece of the next channel group's halo per tap (taps 0..5), the weights two K-tiles ahead
-        if (tap < 6) issue_halo_piece(cg + 1, (cg + 1) & 1, tap);
-        issue_b(kt + 2, slot == 0 ? 2 : slot - 1);
-        slot = slot == 2 ? 0 : slot + 1;
+        // DMA requests behind the MFMAs: one piece of the next channel group's halo per tap (taps 0..4, and 5 for waves 0..2), then
+        // the weights D K-tiles ahead into the slot consumed in the previous iteration
+        if (tap < 5 || (tap == 5 && six)) issue_halo_piece(cg + 1, (cg + 1) & 1, tap < 5 ? tap : 5);
+        issue_b(kt + D, slot == 0 ? RING - 1 : slot - 1);
+        slot = slot == RING - 1 ? 0 : slot + 1;
       }
       if (cg + 1 < cl) {  // tap 8 prefetched into buffer 1; tap 0 of the next group reads buffer 0
 #pragma unroll
