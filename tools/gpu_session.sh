@@ -118,6 +118,14 @@ if has corrpmc; then  # SQ counters of the sampler alone (tools/bench_corr.py mi
   cd $GRAFT_REPO_ROOT
   grep corr_volume_sh gpurun_out/${R}_pmc_corr.txt | head -30
 fi
+if has sqc2; then  # SQ counters per kernel on the C2 workload (encoder kernels visible)
+  cd /tmp && rm -rf /tmp/sqc2 /tmp/sqc2b
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d /tmp/sqc2 -- python $GRAFT_REPO_ROOT/bench.py --workload c2_offline --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /tmp/sqc2.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC --output-format csv -d /tmp/sqc2b -- python $GRAFT_REPO_ROOT/bench.py --workload c2_offline --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /tmp/sqc2b.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/summarize_counters.py /tmp/sqc2 gpurun_out/${R}_sq_counters_c2.txt | grep -E "kernel|conv|enc_" | head -20
+  python tools/summarize_counters.py /tmp/sqc2b gpurun_out/${R}_lds_counters_c2.txt | grep -E "kernel|conv" | head -12
+fi
 if has sq; then
   cd /tmp && rm -rf /tmp/sq /tmp/ldsc
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d /tmp/sq -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-extra-lines > /tmp/sq.log 2>&1
