@@ -477,168 +477,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(CtkConvP p, int tiles
   }
 }
 
-// ---- 64-output-column layers: one tap ROW (three K-tiles, 36 MFMAs per wave) per barrier ------------------------------------
-// conv3x3_halo_kernel<.., N64 = true> issues 12 MFMAs per wave between two barriers; SQ counters (profiles/r04_sq_counters_c2.txt)
-// show its waves stalled 57 % and parked 21 % of their lifetime around those 384 cycles of matrix work.  Here an iteration is
-// (channel group, ky): the weights of its three K-tiles (kx = 0..2) and the A fragments of its three taps are read behind ONE
-// wait + barrier, then 36 MFMAs run back to back.  Weight ring: 8 units of 8 KiB; at the start of an iteration tiles [T, T+5)
-// have been requested, after the barrier T+5 .. T+7 follow into the slots of T-3 .. T-1, then (iterations ky = 0, 1 only) the
-// next channel group's halo pieces, three per iteration (two in the second for the waves that own five).  Wait before the
-// barrier: everything but the two youngest weight tiles and the previous iteration's halo pieces -- vmcnt(2 + hp(previous)).
-template <int EPI>
-__global__ __launch_bounds__(512) void conv3x3_halo64_kernel(CtkConvP p, int tiles_total) {
-  constexpr bool DBG = false;
-  constexpr int BSLOT = 8192, RING = 8;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS_ALL];
-  const CtkGemmP& g = p.g;
-  const int dbg = 0;
-  unsigned jctr = 0;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r32 = lane & 31, half = lane >> 5;
-  const unsigned l3 = lane >> 3, l4 = lane >> 4, l7 = lane & 7;
-  const int cl = p.CL, KT = 9 * cl;
-  const bool six = wave < 3;
-  const int piece0 = six ? 6 * wave : 18 + 5 * (wave - 3);
-  const float w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
-  const float* bias_lds = reinterpret_cast<const float*>(lds + CH_BIAS);
-  if ((EPI & 32) != 0) {
-    for (int i = tid; i < g.N / 4; i += 512) reinterpret_cast<f32x4*>(lds + CH_BIAS)[i] = reinterpret_cast<const f32x4*>(g.bias)[i];
-    __syncthreads();
-  }
-  const unsigned char* in = static_cast<const unsigned char*>(g.A);
-  const unsigned char* wsh = reinterpret_cast<const unsigned char*>(g.Wp) + PP_HDR_BYTES;
-  const unsigned ldw_b = (unsigned)KT * 128;
-  const int ty_tiles = p.Hout / 8, tx_tiles = p.Wout / 32;
-  auto cbyte = [&](const int piece) { return ((l7 ^ ((4 * piece + l4) & 7)) << 4); };
-  const int fswb = (r32 >> 1) & 7;
-  unsigned b_rd0[2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) b_rd0[j][pl] = (unsigned)((wn * 32 + r32) * 128 + (((pl * 4 + j * 2 + half) ^ fswb) << 4));
-
-  f32x16 acc[2][1];
-
-  for (int q = 0;; ++q) {  // my tiles
-    const int G = gridDim.x, first = q * G;
-    if (first >= tiles_total) break;
-    const int n_r = min(G, tiles_total - first);
-    if ((int)blockIdx.x >= n_r) break;
-    unsigned tile = first + ctk_xcd_remap(blockIdx.x, n_r);
-    const int nb = tile % g.nblocks;
-    tile /= g.nblocks;
-    const int tx = tile % tx_tiles;
-    tile /= tx_tiles;
-    const int ty = tile % ty_tiles;
-    const int f = tile / ty_tiles;
-    const int n0 = nb * 128, y0 = ty * 8, x0 = tx * 32;
-
-    long hsrc[6];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      const int r = 8 * (piece0 + e) + (int)l3;
-      const int hy = r / 34, hx = r - hy * 34;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      const bool ok = r < 340 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-      hsrc[e] = ok ? ((long)(f * p.Hin + iy) * p.Win + ix) * cl * 128 : -1;
-    }
-    auto issue_halo_piece = [&](int cg, const int buf, const int e) {
-      cg = min(cg, cl - 1);
-      const int piece = piece0 + e;
-      const unsigned char* src = (hsrc[e] >= 0 ? in + hsrc[e] + (long)cg * 128 : p.zeros) + cbyte(piece);
-      __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + buf * CH_HALO + piece * 1024), 16, 0, 0);
-    };
-    auto issue_b = [&](int kt) {  // one piece per wave: W rows n0 + 8 wave + l3 of K-tile kt -> ring slot kt % 8
-      const int slot = kt & (RING - 1);
-      kt = min(kt, KT - 1);
-      const int cg = kt / 9, tap = kt - cg * 9;
-      const long koff = (long)(tap * cl + cg) * 128;
-      const unsigned char* src = wsh + (long)(n0 + 8 * wave + (int)l3) * ldw_b + koff + cbyte(wave);
-      __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(lds + CH_B0 + slot * BSLOT + wave * 1024), 16, 0, 0);
-    };
-
-#pragma unroll
-    for (int e = 0; e < 5; ++e) issue_halo_piece(0, 0, e);
-    if (six) issue_halo_piece(0, 0, 5);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) issue_b(i);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.0f;
-
-    int T = 0;
-    for (int cg = 0; cg < cl; ++cg) {
-      const unsigned hb = (cg & 1) * CH_HALO;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky, T += 3) {
-        if (ky == 0) PP_WAIT_VM(2);
-        else if (ky == 1) PP_WAIT_VM(5);
-        else if (six) PP_WAIT_VM(5);
-        else PP_WAIT_VM(4);
-        PP_BARRIER();
-        f16x8 fa3[3][2][2][2], fb3[3][2][2];  // [kx][mi][j][plane], [kx][j][plane]
-        unsigned xl = (unsigned)r32;
-        asm volatile("" : "+v"(xl));  // (keeps the per-tap address arithmetic out of loop-invariant hoisting, see conv3x3_halo_kernel)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const unsigned so = CH_B0 + ((T + kx) & (RING - 1)) * BSLOT;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fb3[kx][j][pl] = *reinterpret_cast<const f16x8*>(lds + so + b_rd0[j][pl]);
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const unsigned R = (unsigned)((wm * 2 + mi + ky) * 34 + kx) + xl;
-            const unsigned base = hb + R * 128, sw = (R >> 1) & 7;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int pl = 0; pl < 2; ++pl)
-                fa3[kx][mi][j][pl] = *reinterpret_cast<const f16x8*>(lds + base + ((((unsigned)(pl * 4 + j * 2 + half)) ^ sw) << 4));
-          }
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-              for (int mi = 0; mi < 2; ++mi)
-                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb3[kx][j][term == 0 ? 1 : 0], fa3[kx][mi][j][term == 1 ? 1 : 0], acc[mi][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // requests behind the MFMAs: the weights of tiles T+5 .. T+7 (slots of T-3 .. T-1, consumed before this barrier), then
-        // the next channel group's halo (ky = 0: pieces 0..2; ky = 1: pieces 3, 4 and, for the waves that own six, 5)
-        issue_b(T + 5);
-        issue_b(T + 6);
-        issue_b(T + 7);
-        if (ky == 0) {
-          issue_halo_piece(cg + 1, (cg + 1) & 1, 0);
-          issue_halo_piece(cg + 1, (cg + 1) & 1, 1);
-          issue_halo_piece(cg + 1, (cg + 1) & 1, 2);
-        } else if (ky == 1) {
-          issue_halo_piece(cg + 1, (cg + 1) & 1, 3);
-          issue_halo_piece(cg + 1, (cg + 1) & 1, 4);
-          if (six) issue_halo_piece(cg + 1, (cg + 1) & 1, 5);
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_BARRIER();
-    {
-      const int prow = (f * p.Hout + y0 + wm * 2) * p.Wout + x0;
-      const int ncol = n0 + wn * 32;
-      pp_epilogue<EPI, 2, 1>(g, acc, lane, 0, w_unscale, bias_lds, lds + wave * 4096, [&](int mi) { return prow + mi * p.Wout; },
-                             [&](int ni) { return ncol + ni * 64; }, false, p.n_valid);
-    }
-    PP_BARRIER();
-  }
-}
-
 }  // namespace
 
 // in_sh: SH activations NHWC [F][Hin][Win][Cin/32] lines; wp: ctk_pack_weight of the [Npad][KH*KW*Cin] matrix ([n][ky][kx][c] order,
@@ -687,9 +525,7 @@ extern "C" int ctk_conv2d_sh(const void* in_sh, int32_t F, int32_t Hin, int32_t 
     snprintf(hname, sizeof(hname), "conv_halo_3x3_c%d_n%d", Cin, n_out);
     CtkProfScope hps(hname, flops, 4.0 * ((double)F * Hin * Win * Cin + (double)M * n_out), s);
     const dim3 hgrid((unsigned)(htiles < cus ? htiles : cus));
-    static const bool row64 = [] { const char* e = getenv("CTK_CONV_HALO64"); return !(e && atoi(e) == 0); }();  // dev A/B knob: 0 = one tap per barrier
-    if (n_out <= 64 && row64) hipLaunchKernelGGL((conv3x3_halo64_kernel<32>), hgrid, dim3(512), 0, s, p, (int)htiles);
-    else if (n_out <= 64) hipLaunchKernelGGL((conv3x3_halo_kernel<32, true>), hgrid, dim3(512), 0, s, p, (int)htiles);
+    if (n_out <= 64) hipLaunchKernelGGL((conv3x3_halo_kernel<32, true>), hgrid, dim3(512), 0, s, p, (int)htiles);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<32, false>), hgrid, dim3(512), 0, s, p, (int)htiles);
     CTK_HIP_CHECK_LAUNCH();
     return CTK_OK;
