@@ -199,6 +199,7 @@ def _v2_graphed_window(self, pyr, coords, track_feat, vis, track_mask, point_mas
 
 def _v2_init_online(self):  # cotracker.py:187-191
     self._resolve_deferred_range_check()  # the last chunk of the previous stream (graph streaming defers its check by one call)
+    self._online_batch = None  # B > 1: one state tuple per batch element
     self.online_ind = 0
     self.online_track_feat = None
     self.online_coords_predicted = None
@@ -218,19 +219,34 @@ def _v2_forward(self, video, queries, iters=4, is_train=False, is_online=False):
     if is_online:
         assert T <= S, "Online mode: video chunk must be <= window size."
         assert getattr(self, "online_ind", None) is not None, "Call model.init_video_online_processing() first."
-        if B != 1:
-            raise NotImplementedError("online mode supports B=1")
     self._online_active = bool(is_online)
     # graph streaming: the chunk stream never waits for the GPU (stream_range_check = "immediate": one sync per chunk, transparent re-run)
-    deferred = bool(is_online and self.hip_graph and self.stream_range_check == "deferred")
-    snap = (self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted) if is_online else None
+    deferred = bool(is_online and self.hip_graph and self.stream_range_check == "deferred" and B == 1)
+
+    def snapshot():
+        return (self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted)
 
     def restore(st):
         if st is not None:  # (offline / sliding: no online state to put back before the exact-f32 re-run)
             self.online_ind, self.online_track_feat, self.online_coords_predicted, self.online_vis_predicted = st
 
-    outs = [self._guarded(lambda prec, b=b: self._forward_one(video[b], queries[b], iters, is_online, prec), snap, restore, deferred)
-            for b in range(B)]
+    def run(b):
+        return self._guarded(lambda prec: self._forward_one(video[b], queries[b], iters, is_online, prec),
+                             snapshot() if is_online else None, restore, deferred)
+
+    if is_online and B > 1:
+        # the reference carries the batch inside its online state tensors (cotracker.py:233-259); here every batch element owns a
+        # state tuple that is swapped in around its (independent) window, as CoTrackerThreeOnline does
+        states = getattr(self, "_online_batch", None) or [snapshot()] * B
+        assert len(states) == B, "batch size changed between online calls"
+        outs = []
+        for b in range(B):
+            restore(states[b])
+            outs.append(run(b))
+            states[b] = snapshot()
+        self._online_batch = states
+    else:
+        outs = [run(b) for b in range(B)]
     self.last_logits = (torch.stack([o[1] for o in outs]),)  # pre-sigmoid visibility [B,T,N] (parity tests compare logits)
     return torch.stack([o[0] for o in outs]), torch.sigmoid(self.last_logits[0]), None
 
@@ -342,7 +358,7 @@ def _v2_apply(self, fn, *args, **kwargs):
     return nn.Module._apply(self, fn, *args, **kwargs)
 
 
-_V2_TRANSIENT = {"_packed": type(None), "_graphs": dict, "_hip_encoder": type(None), "_pending_range": type(None)}
+_V2_TRANSIENT = {"_packed": type(None), "_graphs": dict, "_hip_encoder": type(None), "_pending_range": type(None)}  # (online state incl. _online_batch is ordinary tensors: copied)
 
 
 def _v2_getstate(self):  # the packed-weight cache holds ctypes structs with raw pointers: never pickled / deep-copied

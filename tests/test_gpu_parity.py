@@ -1202,6 +1202,31 @@ def test_cotracker2_model_sliding_and_streaming(golden, precision):
     assert maxdiff(logit(vs), logit(g["stream_vis"])) < 2e-4
 
 
+def test_cotracker2_online_batched_streaming(golden, precision):
+    """CoTracker2 online mode with B = 2 (the reference batches its online state tensors, cotracker.py:233-259): each batch element
+    keeps its own state, so a batched stream equals the two single-video streams bit for bit."""
+    g = golden("cotracker2")
+    m = _v2_model(precision)
+    v0, q0 = t(g["video"]), t(g["queries"])
+    v1 = v0.flip(1).contiguous()
+    q1 = q0.clone()
+    q1[..., 1] = 95.0 - q1[..., 1]
+    single = []
+    for v, q in ((v0, q0), (v1, q1)):
+        m.init_video_online_processing()
+        for ind in range(0, v.shape[1] - 4, 4):
+            out = m(v[:, ind:ind + 8], q, iters=1, is_online=True)
+        single.append(out)
+    assert maxdiff(single[0][0], g["stream_coords"]) < 1e-3
+    m.init_video_online_processing()
+    vb, qb = torch.cat([v0, v1]), torch.cat([q0, q1])
+    for ind in range(0, vb.shape[1] - 4, 4):
+        cb, vbv, _ = m(vb[:, ind:ind + 8], qb, iters=1, is_online=True)
+    assert cb.shape[0] == 2
+    for b in range(2):
+        assert torch.equal(cb[b], single[b][0][0]) and torch.equal(vbv[b], single[b][1][0])
+
+
 def test_cotracker2_damped_heads_four_iterations(golden, precision):
     """CoTracker2 over FOUR iterations per window (sliding, streaming direct, streaming hipGraph) against the reference.
     With random weights the CoTracker2 map is chaotic even with damped feedback (heads x0.25, track_feat_updater x0.1,
