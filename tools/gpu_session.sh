@@ -69,18 +69,6 @@ PY
     python -c "import json; d=json.load(open('gpurun_out/${R}_bench_c4_deep64_$1_ov$2.json')); print('C4 DEEP64=$1 OVERLAP=$2', d['value'], d['ms_per_step'])"
   done
 fi
-if has halo64ab; then  # 64-column 3x3 layers: one tap per barrier (CTK_CONV_HALO64=0) vs a tap row per barrier (default)
-  for v in 0 1 0 1; do
-    (CTK_CONV_HALO64=$v timeout 600 python bench.py --workload c2_offline --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/${R}_halo64ab_$v.err | tail -1) > gpurun_out/${R}_bench_c2_halo64_$v.json
-    python - gpurun_out/${R}_bench_c2_halo64_$v.json $v <<'PY'
-import json, sys
-d = json.load(open(sys.argv[1]))
-print("CTK_CONV_HALO64=" + sys.argv[2], d["ms_per_step"], "ms/step; parity", json.dumps(d.get("parity", {}).get("timed_step", {}))[-420:-300])
-for k in d["kernels"]:
-    if k["name"].startswith(("conv_halo",)): print("    ", k["name"], k["launches"], k["total_ms"], k["avg_us"], k["tflops"])
-PY
-  done
-fi
 if has haloab; then  # 3x3 convolutions: halo kernel (default) vs conv_pp128_kernel (CTK_CONV_HALO=0), C2 and the encoder alone
   for v in 0 1 0 1; do
     (CTK_CONV_HALO=$v timeout 600 python bench.py --workload c2_offline --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/${R}_haloab_$v.err | tail -1) > gpurun_out/${R}_bench_c2_halo_$v.json
