@@ -83,12 +83,17 @@ int stream_follow(hipStream_t from, hipStream_t to) {
 
 // Knob CTK_OVERLAP (read per call): 0 = ignore aux_stream (everything on the caller's stream), bit 1 = software
 // pipeline sampler || corr_mlp, bit 2 = points<-virtual query projection beside the virtual-track chain, bit 4 (round 4) =
-// the time blocks' q projection beside their kv projection (tail filling between two persistent GEMMs).
+// the time blocks' q projection beside their kv projection (tail filling between two persistent GEMMs), bit 8 (round 4) = the
+// points<-virtual query projection beside the SMALL launches of the virtual-track chain only, on a limited number of CUs.
 // DEFAULT 0: measured on MI355X at C3 (profiles/r02_overlap_and_time_attention_ab.txt) the sampler and the corr_mlp GEMM
 // do NOT complement each other -- run side by side each slows down by more than the other gains (sampler 2.70 -> 4 x
 // 1.21 ms, fc1 2.24 -> 4 x 0.77 ms per iteration; step 1528.5 -> 1547.3 ms) -- and the side query projection is worth
 // 0.15 % (1526.1 ms), inside run-to-run noise.  Results are bit-identical in every mode (tests), so the code stays
 // as an opt-in for other shapes.
+int side_cus() {  // CTK_SIDE_CUS (dev knob, read once): workgroups the side projection's persistent GEMM may occupy in overlap mode 8
+  static const int n = [] { const char* e = getenv("CTK_SIDE_CUS"); return e ? atoi(e) : 192; }();
+  return n;
+}
 int overlap_mode() {  // dev knob, read ONCE (getenv on the enqueue path races with setenv in multithreaded hosts)
   static const int mode = [] { const char* e = getenv("CTK_OVERLAP"); return e ? atoi(e) : 0; }();
   return mode;
@@ -271,14 +276,24 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     // chain below (virtual<-points attention, two 1024-row MLPs, virtual self attention: ~16 launches that occupy a
     // fraction of the chip), into its own xn2 buffer and the (otherwise unused) q columns of the point rows of qkv.
     if (!fr.space_attn) continue;
-    const bool side_q = fr.aux != nullptr && (overlap_mode() & 2) != 0;
+    // Two placements of that side work (both bit-identical to the single-stream order: same launches, same inputs):
+    //   bit 2: forked at the start of the space block -- measured useless (profiles/r02_overlap_and_time_attention_ab.txt): its
+    //          persistent to_q kernel and the main stream's persistent to_kv kernel each want every CU's whole LDS and serialise;
+    //   bit 8 (round 4): forked BEHIND the virtual<-points attention, i.e. beside the ~16 small launches of the virtual-track chain
+    //          only, and with the persistent GEMM limited to side_cus() workgroups (CtkPPCuLimit) so that the chain's kernels --
+    //          which cannot share a CU with a workgroup that owns all of its LDS -- find free CUs.
+    const bool late_q = fr.aux != nullptr && (overlap_mode() & 8) != 0;
+    const bool side_q = late_q || (fr.aux != nullptr && (overlap_mode() & 2) != 0);
     JoinGuard side{s, fr.aux};
-    if (side_q) {
+    auto side_work = [&]() -> int {
       const ctk_block_weights& b = w->point2virtual[i];
       CTK_TRY(side.fork());
+      CtkPPCuLimit lim(late_q ? side_cus() : 0);
       CTK_TRY(ctk_layernorm(tok, ws.xn2, P, nullptr, nullptr, 1e-6f, sp, fr.aux));                                          // norm1(points)
       CTK_TRY(gemm(ws.xn2, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, fr.aux, nullptr, 0, 1, 0, 0, 0, sp, false));
-    }
+      return CTK_OK;
+    };
+    if (side_q && !late_q) CTK_TRY(side_work());
     // ---- virtual <- points cross attention                          cotracker.py:510-512
     {
       const ctk_block_weights& b = w->virtual2point[i];
@@ -289,6 +304,7 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
       // batch = frame t; query i = virtual track (row P + i*S + t); key j = point (row j*S + t)
       CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S, CTK_VIRT, N,
                    v2p_splits(N), ws.partial, s, sp, fr.point_mask, nullptr));  // mask over KEYS (cotracker.py:566-569)
+      if (late_q) CTK_TRY(side_work());  // the auxiliary stream follows the attention; the small launches below run beside it
       CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
                    tok + P * CTK_HID, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(mlp_block(ws, P, V, b, s, sp));

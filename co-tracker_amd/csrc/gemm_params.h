@@ -67,6 +67,16 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s);
 // Stream-K scratch of the persistent kernels: the entry points that own a workspace lend a piece of it for the duration of
 // the call (thread-local; zeroes the flags on `s`).  Only launches on that stream use it; without one the kernels deal whole
 // tiles in rounds.
+// Limits the workgroups of the persistent GEMMs launched by this thread while in scope (0 = no limit): a persistent workgroup owns
+// its CU's whole LDS, so a launch on every CU locks everything else out of the chip for its whole duration; api.hip's overlap
+// mode 8 leaves some CUs to the small launches of the virtual-track chain.  Results do not depend on the grid size.
+struct CtkPPCuLimit {
+  explicit CtkPPCuLimit(int n);
+  ~CtkPPCuLimit();
+  CtkPPCuLimit(const CtkPPCuLimit&) = delete;
+  CtkPPCuLimit& operator=(const CtkPPCuLimit&) = delete;
+  int prev_;
+};
 size_t ctk_pp_scratch_bytes();
 size_t ctk_pp_scratch_bytes_if_enabled();
 struct CtkPPScratchScope {

@@ -580,6 +580,8 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+thread_local int t_pp_cu_limit = 0;
+
 int pp_num_cus() {
   static const int n = [] {
     int dev = 0, cu = 0;
@@ -596,6 +598,9 @@ thread_local size_t t_sk_bytes = 0;
 thread_local hipStream_t t_sk_stream = nullptr;
 
 }  // namespace
+
+CtkPPCuLimit::CtkPPCuLimit(int n) : prev_(t_pp_cu_limit) { t_pp_cu_limit = n; }
+CtkPPCuLimit::~CtkPPCuLimit() { t_pp_cu_limit = prev_; }
 
 size_t ctk_pp_scratch_bytes() { return (size_t)PP_SK_FLAG_BYTES + (size_t)pp_num_cus() * PP_SK_SLOT_MAX; }
 // what a window / update-former workspace reserves for it: nothing unless the opt-in stream-K walk (mode bit 4) is on at
@@ -660,7 +665,8 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   const long tiles = (long)mblocks * nblocks * g.batch;
   const int cus = pp_num_cus();
   if (tiles < cus) return -1;  // less than one tile per CU (virtual-track GEMMs, short streaming windows): the 64x64 / 128x128 kernels fill the chip better (tools/gemm_lab.cpp)
-  const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), blk(512);
+  const int wgs = (t_pp_cu_limit > 0 && t_pp_cu_limit < cus) ? t_pp_cu_limit : cus;  // (CtkPPCuLimit: leave CUs to concurrent small launches)
+  const dim3 grid((unsigned)(tiles < wgs ? tiles : wgs)), blk(512);
   const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
   if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
   if (!pp_epi_supported(code)) return -1;

@@ -53,6 +53,13 @@ if has ovab; then  # CTK_OVERLAP bit 4: time-block q projection beside the kv pr
     python -c "import json,sys; d=json.load(open('gpurun_out/${R}_bench_c3_overlap_$v.json')); print('CTK_OVERLAP=$v', d['value'], d['ms_per_step'], json.dumps(d['parity']['timed_step'])[-330:-200])"
   done
 fi
+if has lateab; then  # CTK_OVERLAP bit 8: points<-virtual query projection beside the small launches of the virtual-track chain, on CTK_SIDE_CUS CUs
+  for v in "0 192" "8 192" "8 224" "8 160" "0 192" "8 192" "8 128"; do
+    set -- $v
+    (CTK_OVERLAP=$1 CTK_SIDE_CUS=$2 timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile --no-extra-lines 2>gpurun_out/${R}_lateab.err | tail -1) > gpurun_out/${R}_bench_c3_late_$1_$2.json
+    python -c "import json; d=json.load(open('gpurun_out/${R}_bench_c3_late_$1_$2.json')); print('CTK_OVERLAP=$1 CTK_SIDE_CUS=$2', d['value'], d['ms_per_step'], d['parity']['timed_step']['coords_px'], d['parity']['timed_step']['vis_logit'])"
+  done
+fi
 if has deepab; then  # small-M GEMM kernel: round-3 ring (CTK_GEMM_DEEP64=4) vs 8 slots / 2 K-tiles per iteration (82, default); C4 also with CTK_OVERLAP=2
   for v in 4 82 4 82; do
     (CTK_GEMM_DEEP64=$v timeout 600 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra-lines 2>gpurun_out/${R}_deepab_c3_$v.err | tail -1) > gpurun_out/${R}_bench_c3_deep64_$v.json
