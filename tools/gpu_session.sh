@@ -53,6 +53,12 @@ if has ovab; then  # CTK_OVERLAP bit 4: time-block q projection beside the kv pr
     python -c "import json,sys; d=json.load(open('gpurun_out/${R}_bench_c3_overlap_$v.json')); print('CTK_OVERLAP=$v', d['value'], d['ms_per_step'], json.dumps(d['parity']['timed_step'])[-330:-200])"
   done
 fi
+if has latetrace; then  # kernel trace of one step with overlap mode 8: do the two queues overlap in time?
+  cd /tmp && rm -rf /tmp/kt
+  CTK_OVERLAP=8 CTK_SIDE_CUS=160 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-extra-lines > /tmp/kt.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/trace_overlap.py /tmp/kt | tee gpurun_out/${R}_overlap8_trace.txt
+fi
 if has lateab; then  # CTK_OVERLAP bit 8: points<-virtual query projection beside the small launches of the virtual-track chain, on CTK_SIDE_CUS CUs
   for v in "0 192" "8 192" "8 224" "8 160" "0 192" "8 192" "8 128"; do
     set -- $v
