@@ -599,6 +599,22 @@ int launch_with_lds(K kernel, unsigned blocks, unsigned threads, size_t lds_byte
 }
 }  // namespace
 
+// 64 x 64 tiles (SH operands): the 64 S-row virtual-track Linears, and the tail rows a persistent launch of gemm_pp.hip
+// leaves when its tile count is a little more than a whole number of rounds (ctk_launch_gemm_pp)
+int ctk_launch_gemm_sh64(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
+  g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
+  char pname[32];
+  snprintf(pname, sizeof(pname), "gemm_sh_64_k%d_n%d", g.K, g.N);
+  CtkProfScope ps(pname, flops, bytes, s);
+  static const int deep = [] { const char* e = getenv("CTK_GEMM_DEEP64"); return e ? atoi(e) : 4; }();  // dev knob, read once: 0 = 2-stage kernel, 4 / 8 = stages
+  const dim3 grid((unsigned)((long)g.mblocks * g.nblocks * g.batch));
+  if (deep >= 8) hipLaunchKernelGGL((gemm_sh_deep64_kernel<8>), grid, dim3(256), 0, s, g);
+  else if (deep >= 4) hipLaunchKernelGGL((gemm_sh_deep64_kernel<4>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1, 2>), grid, dim3(256), 0, s, g);
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}
+
 int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   // recorder rows are per (tile, K, N): the K = 384 Linears and corr_mlp.fc1 (K = 2432) sit at very different
   // fractions of the MFMA ceiling and must not be averaged under one name
@@ -725,12 +741,7 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
       }
 #undef CTK_SH128
     } else {
-      g.mblocks = (g.M + 63) / 64; g.nblocks = g.N / 64;
-      CtkProfScope ps(prof_name("64"), flops, bytes, s);
-      static const int deep = [] { const char* e = getenv("CTK_GEMM_DEEP64"); return e ? atoi(e) : 4; }();  // dev knob, read once: 0 = 2-stage kernel, 4 / 8 = stages
-      if (deep >= 8) hipLaunchKernelGGL((gemm_sh_deep64_kernel<8>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
-      else if (deep >= 4) hipLaunchKernelGGL((gemm_sh_deep64_kernel<4>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1, 2>), dim3((unsigned)((long)g.mblocks * g.nblocks * g.batch)), dim3(256), 0, s, g);
+      return ctk_launch_gemm_sh64(g, flops, bytes, s);
     }
   } else if (big) {
     g.mblocks = (g.M + 127) / 128; g.nblocks = g.N / 128;

@@ -62,6 +62,7 @@ struct CtkGemmP {
 
 // gemm_f16x3.hip
 int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s);
+int ctk_launch_gemm_sh64(CtkGemmP& g, double flops, double bytes, hipStream_t s);  // 64 x 64 tiles (SH operands)
 // gemm_pp.hip: persistent ping-pong kernels; returns -1 when the shape is not theirs (caller falls back)
 int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s);
 // Stream-K scratch of the persistent kernels: the entry points that own a workspace lend a piece of it for the duration of

@@ -591,7 +591,7 @@ int pp_num_cus() {
   return n;
 }
 
-int g_pp_mode = [] { const char* e = getenv("CTK_GEMM_PP"); return e ? atoi(e) : 1; }();  // (env: initial value, read once) bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; bit 4 (16): stream-K walk where a scratch buffer was lent (OFF by default, see the tile walk); experiments: bit 1 = no stores, bit 3 = timing jitter, bits 8.. = start stagger
+int g_pp_mode = [] { const char* e = getenv("CTK_GEMM_PP"); return e ? atoi(e) : 33; }();  // (env: initial value, read once) bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; bit 5 (32): tail split (see ctk_launch_gemm_pp); bit 4 (16): stream-K walk where a scratch buffer was lent (OFF by default, see the tile walk); experiments: bit 1 = no stores, bit 3 = timing jitter, bits 8.. = start stagger
 
 thread_local void* t_sk_mem = nullptr;
 thread_local size_t t_sk_bytes = 0;
@@ -654,6 +654,17 @@ static bool pp_epi_supported(int code) {
          code == pp_epi(CTK_ACT_NONE, true, false, false, true) || code == pp_epi(CTK_ACT_GELU_TANH, false, true, false, true);
 }
 
+// Tail split (g_pp_mode bit 5, default ON).  A persistent launch deals whole 256-row tiles in rounds of #CUs: the N = 384
+// Linears of a C3 window are 800 / 808 tiles = 3 full rounds + a round that is 1/8 full, and the launch lasts four tile times
+// (profiles/r03_gemm_lab_streamk.txt: mlp.fc2 350 us for 768 tiles, 414 us for 800).  When the last round would be at most
+// CTK_GEMM_TAIL_PCT % full (default 25), the persistent kernel gets the whole rounds only and the remaining row blocks go to the
+// 64 x 64-tile kernel of gemm_f16x3.hip (same split-half arithmetic, same K order inside a row), which spreads them over
+// every CU.  Rows are independent, so the result does not depend on where the cut is.
+static int pp_tail_pct() {
+  static const int pct = [] { const char* e = getenv("CTK_GEMM_TAIL_PCT"); return e ? atoi(e) : 25; }();
+  return pct;
+}
+
 // Returns CTK_OK after launching, or -1 when the shape is not one of the persistent kernels' (caller falls back).
 int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   if ((g_pp_mode & 1) == 0 || !g.a_split || !g.Wp) return -1;
@@ -661,25 +672,46 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   if ((!t256 && !t192) || g.N * 4 > PP_BIAS_BYTES) return -1;
   if (g.lda * 2 > 0xffffff) return -1;  // row offsets are formed with 32-bit arithmetic inside a tile
   const int BN = t256 ? 256 : 192;
-  const int mblocks = (g.M + 255) / 256, nblocks = g.N / BN;
-  const long tiles = (long)mblocks * nblocks * g.batch;
+  int mblocks = (g.M + 255) / 256;
+  const int nblocks = g.N / BN;
+  long tiles = (long)mblocks * nblocks * g.batch;
   const int cus = pp_num_cus();
   if (tiles < cus) return -1;  // less than one tile per CU (virtual-track GEMMs, short streaming windows): the 64x64 / 128x128 kernels fill the chip better (tools/gemm_lab.cpp)
   const int wgs = (t_pp_cu_limit > 0 && t_pp_cu_limit < cus) ? t_pp_cu_limit : cus;  // (CtkPPCuLimit: leave CUs to concurrent small launches)
-  const dim3 grid((unsigned)(tiles < wgs ? tiles : wgs)), blk(512);
   const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
   if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
   if (!pp_epi_supported(code)) return -1;
+  // ---- tail split: whole rounds here, the row blocks of a nearly empty last round as 64 x 64 tiles
+  CtkGemmP tail = g;
+  int tail_rows = 0;
+  const long rem = tiles % wgs;
+  if ((g_pp_mode & 32) != 0 && g.batch == 1 && tiles > wgs && rem > 0 && rem * 100 <= (long)wgs * pp_tail_pct()) {
+    const int mb_full = (int)((tiles - rem) / nblocks);  // row blocks of the whole rounds (rounded down to whole row blocks)
+    const long rows_full = (long)mb_full * 256;
+    if (mb_full > 0 && (!g.bias_rows || rows_full % g.bias_period == 0)) {
+      tail_rows = (int)(g.M - rows_full);
+      tail.M = tail_rows;
+      tail.A = static_cast<const unsigned char*>(g.A) + rows_full * g.lda * 2;  // (a_split: lda counts halves)
+      tail.C = static_cast<unsigned char*>(g.C) + rows_full * g.ldc * (g.c_split ? 2 : 4);
+      if (g.resid) tail.resid = g.resid + rows_full * g.ldr;
+      g.M = (int)rows_full;
+      mblocks = mb_full;
+      tiles = (long)mblocks * nblocks;
+    }
+  }
+  const double frac = tail_rows ? (double)g.M / (double)(g.M + tail_rows) : 1.0;
+  {
+  const dim3 grid((unsigned)(tiles < wgs ? tiles : wgs)), blk(512);
   // every eligibility check is done: only now touch g and open the profile row (a fallback to gemm_f16x3.hip must not leave
   // a phantom gemm_sh_pp* row or a changed tile grid behind)
   g.mblocks = mblocks;
   g.nblocks = nblocks;
   char pname[40];
   snprintf(pname, sizeof(pname), "gemm_sh_pp%d_k%d_n%d", BN, g.K, g.N);
-  CtkProfScope ps(pname, flops, bytes, s);
+  CtkProfScope ps(pname, flops * frac, bytes * frac, s);
   // stream-K only on the stream whose entry point lent the scratch (one persistent GEMM at a time uses the slots)
   g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;
-  const bool dbgk = (g_pp_mode & ~17) != 0;
+  const bool dbgk = (g_pp_mode & ~(17 | 32)) != 0;
 #define PP_CASE(E)                                                                                             \
   case E:                                                                                                      \
     if (t256 && dbgk) hipLaunchKernelGGL((gemm_pp256_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);   \
@@ -700,5 +732,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   }
 #undef PP_CASE
   CTK_HIP_CHECK_LAUNCH();
+  }
+  if (tail_rows) return ctk_launch_gemm_sh64(tail, flops * (1.0 - frac), bytes * (1.0 - frac), s);
   return CTK_OK;
 }
