@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctk_hip.so")
+# CTK_LIB_PATH: dev knob for A/B runs of two builds in one GPU session (tools/gpu_session.sh); never set in product use
+LIB_PATH = os.environ.get("CTK_LIB_PATH") or os.path.join(_HERE, "libctk_hip.so")
 
 LEVELS = 4
 DEPTH = 3

@@ -13,6 +13,8 @@ int ctk_launch_pyramid_split(const float* fmap, long pixels, void* out, hipStrea
 int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh, int n0, int ncount, void* out,
                               long level_stride_halves, hipStream_t s);
 int ctk_launch_virtual_init(const float* vt, int S, float* dst, hipStream_t s);
+int ctk_launch_layernorm2(const float* x, void* y, long R, const float* gamma, const float* beta, float eps, void* y2, float eps2,
+                          int out_split, hipStream_t s);
 int ctk_launch_heads(const float* tokens, const float* hw, const float* hb, int S, int N, float* delta, float* coords,
                      float* vis, float* conf, hipStream_t s);
 
@@ -298,7 +300,10 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     {
       const ctk_block_weights& b = w->virtual2point[i];
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, nullptr, nullptr, 1e-6f, sp, s));   // norm1(virtual)
-      CTK_TRY(ctk_layernorm(tok, xn, P, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));                        // norm_context(points)
+      // norm_context(points) -- and, from the same read of the point tokens (the virtual-track chain below does not touch them),
+      // norm1(points) of this depth's points<-virtual block into xn2 (round 5: one pass, two norms)
+      if (!side_q) CTK_TRY(ctk_launch_layernorm2(tok, xn, P, b.ctx_gamma, b.ctx_beta, 1e-5f, ws.xn2, 1e-6f, sp, s));
+      else CTK_TRY(ctk_layernorm(tok, xn, P, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));                   // norm_context(points)
       CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv + P * QL, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       // batch = frame t; query i = virtual track (row P + i*S + t); key j = point (row j*S + t)
@@ -324,9 +329,8 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     // ---- points <- virtual cross attention                          cotracker.py:515-517
     {
       const ctk_block_weights& b = w->point2virtual[i];
-      if (!side_q) CTK_TRY(ctk_layernorm(tok, xn, P, nullptr, nullptr, 1e-6f, sp, s));                                 // norm1(points)
       CTK_TRY(ctk_layernorm(tok + P * CTK_HID, xn + P * CTK_HID, V, b.ctx_gamma, b.ctx_beta, 1e-5f, sp, s));           // norm_context(virtual)
-      if (!side_q) CTK_TRY(gemm(xn, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      if (!side_q) CTK_TRY(gemm(ws.xn2, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));  // xn2 = norm1(points), written beside norm_context(points) above
       else CTK_TRY(side.join());  // join: q(points) is ready
       CTK_TRY(gemm(xn + P * CTK_HID, CTK_HID, (int)V, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + P * QL + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(attn(qkv, QL, 1, S, qkv + P * QL + CTK_HID, qkv + P * QL + 2 * CTK_HID, QL, 1, S, att, 1, S, S, N, CTK_VIRT, 1, nullptr, s, sp,

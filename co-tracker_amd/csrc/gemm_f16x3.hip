@@ -461,7 +461,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_sh_kernel(CtkGemmP g) {
 // gemm_sh_kernel<2,2,1,1,2> spends a whole LDS-DMA latency per K-tile there when its operands are cold (6 MFMAs per wave
 // and K-tile cannot hide an L2 miss behind two stages).  Same tile and fragment layout, but NS stages of 16 KiB: NS - 1
 // K-tiles are always in flight behind a counted vmcnt, one raw barrier per K-tile.
-template <int NS>
+template <int NS, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(256) void gemm_sh_deep64_kernel(CtkGemmP g) {
   constexpr int BM = 64, BN = 64, STAGE = (BM + BN) * 128, GPW = 4;  // 16 pieces of 8 rows per K-tile, 4 per wave
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
@@ -533,7 +533,10 @@ __global__ __launch_bounds__(256) void gemm_sh_deep64_kernel(CtkGemmP g) {
     st = (st + 1 == NS) ? 0 : st + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the duplicate tail requests
-  gemm_epilogue<1, 1>(g, acc, m0 + wm * 32, n0 + wn * 32, r32, half, bz);
+  // (compile-time epilogues for the six Linear flavours: the same arithmetic, bit for bit, as gemm_sh_kernel's and the
+  // persistent kernels' -- the tail rows of a split launch must not differ from the rows the persistent kernel wrote)
+  if (EPI == EPI_GENERIC) gemm_epilogue<1, 1>(g, acc, m0 + wm * 32, n0 + wn * 32, r32, half, bz);
+  else gemm_epilogue_c<1, 1, EPI>(g, acc, m0 + wm * 32, n0 + wn * 32, r32, half, bz);
 }
 
 // A persistent variant (resident workgroups walking over the tiles, the next tile's first two K-tiles prefetched by DMA
@@ -609,7 +612,20 @@ int ctk_launch_gemm_sh64(CtkGemmP& g, double flops, double bytes, hipStream_t s)
   static const int deep = [] { const char* e = getenv("CTK_GEMM_DEEP64"); return e ? atoi(e) : 4; }();  // dev knob, read once: 0 = 2-stage kernel, 4 / 8 = stages
   const dim3 grid((unsigned)((long)g.mblocks * g.nblocks * g.batch));
   if (deep >= 8) hipLaunchKernelGGL((gemm_sh_deep64_kernel<8>), grid, dim3(256), 0, s, g);
-  else if (deep >= 4) hipLaunchKernelGGL((gemm_sh_deep64_kernel<4>), grid, dim3(256), 0, s, g);
+  else if (deep >= 4) {
+    const int code = epi_code(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
+#define CTK_SH64(E) hipLaunchKernelGGL((gemm_sh_deep64_kernel<4, E>), grid, dim3(256), 0, s, g)
+    switch (code) {
+      case epi_code(CTK_ACT_GELU_ERF, false, true, false, true): CTK_SH64(epi_code(CTK_ACT_GELU_ERF, false, true, false, true)); break;    // corr_mlp.fc1
+      case epi_code(CTK_ACT_NONE, false, true, false, true): CTK_SH64(epi_code(CTK_ACT_NONE, false, true, false, true)); break;            // corr_mlp.fc2 -> x
+      case epi_code(CTK_ACT_NONE, false, false, true, false): CTK_SH64(epi_code(CTK_ACT_NONE, false, false, true, false)); break;          // input_transform
+      case epi_code(CTK_ACT_NONE, false, false, false, true): CTK_SH64(epi_code(CTK_ACT_NONE, false, false, false, true)); break;          // to_q / to_kv
+      case epi_code(CTK_ACT_NONE, true, false, false, true): CTK_SH64(epi_code(CTK_ACT_NONE, true, false, false, true)); break;            // to_out / mlp.fc2 (+ residual)
+      case epi_code(CTK_ACT_GELU_TANH, false, true, false, true): CTK_SH64(epi_code(CTK_ACT_GELU_TANH, false, true, false, true)); break;  // mlp.fc1
+      default: CTK_SH64(EPI_GENERIC);
+    }
+#undef CTK_SH64
+  }
   else hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 1, 2>), grid, dim3(256), 0, s, g);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;

@@ -21,6 +21,7 @@
 //     twice instead of three times).
 // Same numerics as gemm_f16x3.hip (3 x v_mfma_f32_32x32x16_f16 per product, small terms first within a k-step).
 #include "pp_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -151,7 +152,9 @@ __device__ __forceinline__ void pp_cursor_next(const CtkGemmP& g, const PPWalk& 
 // ordinary epilogue (pp_epilogue_io routed to the slot) and added by the ordinary epilogue of the owner.  Wave w of the
 // consumer reads exactly the elements wave w of the producer wrote (same wave tile), so each wave has its own flag and no
 // workgroup barrier is needed in the epilogue.  Only the kernels whose epilogue is linear with an f32 output take part.
-constexpr bool pp_sk_epi(int EPI) { return (EPI & 3) == 0 && (EPI & 8) == 0 && (EPI & 16) == 0 && (EPI & 32) != 0; }
+// (round 5: not the "+ residual" Linears any more -- their tiles must start at K-tile 0, where the residual rides on the first
+// K-tiles (gemm_pp192_kernel); the tail split of ctk_launch_gemm_pp gives them what stream-K gave, without a spin-wait)
+constexpr bool pp_sk_epi(int EPI) { return (EPI & 3) == 0 && (EPI & 4) == 0 && (EPI & 8) == 0 && (EPI & 16) == 0 && (EPI & 32) != 0; }
 
 __device__ __forceinline__ unsigned char* pp_sk_slot(const CtkGemmP& g, const int slot) {
   return static_cast<unsigned char*>(g.sk) + PP_SK_FLAG_BYTES + (long)slot * PP_SK_SLOT_MAX;
@@ -498,9 +501,60 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   f32x16 acc[2][3];
   auto row_of = [&](int mi) { return tile.m0 + wm * 64 + mi * 32; };
   auto col_of = [&](int ni) { return tile.n0 + wn * 32 + ni * 64; };
-  PPResid<2, 3> resid;
-  auto resid_issue = [&]() { pp_resid_issue<EPI, 2, 3>(g, resid, lane, tile.bz, row_of, col_of); };
-  auto init_acc = [&](const float sc) { pp_init_acc<EPI, 2, 3>(acc, resid, lane, sc, lds + RING + PP_BIAS_BYTES + wave * 4096); };
+  // ---- residual (EPI bit 2), round 5.  Until round 4 the NEXT tile's residual (196 KiB per workgroup) was requested in one burst
+  // in front of the epilogue and transposed into the accumulators right behind it -- a fully exposed burst with the matrix pipe
+  // idle (tools/gemm_lab: to_out 148 us against 111 us for the same Linear without residual).  Holding it in registers across
+  // the main loop instead does not fit (96 + 48 + 96 registers: hipcc spills, and a spilled load is a vmcnt(0) in the hot loop).
+  // Now the CURRENT tile's residual rides on the tile's first eight K-tiles, one 32 x 32 sub-tile k = (mi, ni) at a time:
+  //   K-tile k,     phase 1: its four 1-KiB line pieces are requested (asm loads: hipcc must neither count nor wait for them);
+  //   K-tile k + 1, phase 1: (landed: the counted wait of phase 0 retired them) scaled by s, written to the wave's LDS image;
+  //   K-tile k + 1, phase 2 (ni = 2: K-tile k + 2, phase 0): read back in accumulator layout and ADDED to acc[mi][ni] behind the
+  //                          phase's MFMAs, which work on another column block.
+  // 16 + 16 registers for three phases, four loads per wave and K-tile beside 7 DMA pieces; the wait of the phase behind the
+  // loads leaves 4 more operations in flight (vmcnt 9: the loads are younger than the two DMA pieces that may stay in flight
+  // with them), every other wait is unchanged.  tools/check_pp_schedule.py replays this program.
+  constexpr bool RP = (EPI & 4) != 0;
+  f32x4 rp[4], rv[4];
+  unsigned char* const scr = lds + RING + PP_BIAS_BYTES + wave * 4096;
+  const int rrow = lane >> 3, rchunk = lane & 7, rsw = r32 & 7;
+  auto res_load = [&](auto k_tag) {
+    constexpr int k = decltype(k_tag)::value, mi = k / 3, ni = k % 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rowc = min(row_of(mi) + rrow + 8 * i, g.M - 1);
+      const float* ptr = g.resid + (long)tile.bz * g.c_bs + (long)rowc * g.ldr + rchunk * 4 + col_of(ni);
+      f32x4 t;  // (an asm operand inside a generic lambda cannot name a captured variable)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(ptr) : "memory");
+      rp[i] = t;
+    }
+  };
+  auto res_write = [&]() {  // row r = rrow + 8 i, chunk c at position c ^ (r & 7) (as pp_init_acc)
+    asm volatile("" : "+v"(rp[0]), "+v"(rp[1]), "+v"(rp[2]), "+v"(rp[3]));  // no consumer above this point
+    unsigned char* wr = scr + rrow * 128 + ((rchunk ^ rrow) << 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(wr + i * 1024) = rp[i] * w_scale;
+  };
+  auto res_read = [&]() {
+    const unsigned char* rd = scr + r32 * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(rd + (((2 * q + half) ^ rsw) << 4));
+  };
+  auto res_add = [&](auto k_tag) {
+    constexpr int k = decltype(k_tag)::value, mi = k / 3, ni = k % 3;
+    PP_SCHED_FENCE();  // behind the MFMAs of the phase, not in front of them
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mi][ni][q * 4 + e] += rv[q][e];
+  };
+  auto init_acc = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+  };
   auto mma = [&](const int n) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -526,53 +580,78 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     c2 = c1;
     pp_cursor_next<BM, BN>(g, walk, c2);
   }
-  resid_issue();
-  init_acc(tile.kb > 0 ? 0.0f : w_scale);
+  init_acc();
   set_rd(0);
   PP_WAIT_VM(5);  // I0, I1 of K-tile 0 landed (I2: 2 pieces and I0 of K-tile 1: 3 pieces may be in flight)
   PP_BARRIER();
   if (grp == 1) PP_BARRIER();
 
   int par = 0;
+  int kt = 0;
+  // One K-tile; I = its index inside the tile when it carries residual work (0..7), -1 otherwise.
+  auto ktile = [&](auto i_tag) {
+    constexpr int I = decltype(i_tag)::value;
+    constexpr bool LD = RP && I >= 0 && I <= 5;                     // request sub-tile I
+    constexpr bool WR = RP && I >= 1 && I <= 6;                     // sub-tile I - 1 -> LDS image
+    constexpr bool RD2 = RP && (I == 1 || I == 2 || I == 4 || I == 5);  // sub-tile I - 1 (ni != 2): read back + add in phase 2
+    constexpr bool RD0 = RP && (I == 4 || I == 7);                      // sub-tile I - 2 (ni == 2): read back + add in phase 0
+    // ---- phase 0: read A, B_0; issue I1 of K-tile J+1; wait for I2 of this K-tile
+    read_a();
+    read_b(0);
+    if constexpr (RD0) res_read();
+    issue_i1(c1, par ^ 1);
+    PP_WAIT_VM(5);
+    PP_BARRIER();
+    PP_WAIT_LGKM0();
+    mma(0);
+    if constexpr (RD0) res_add(std::integral_constant<int, (RD0 ? I - 2 : 0)>{});
+    PP_BARRIER();
+    // ---- phase 1: read B_1; issue I2 of K-tile J+1
+    read_b(1);
+    issue_i2(c1, par ^ 1);
+    if constexpr (WR) res_write();
+    if constexpr (LD) res_load(std::integral_constant<int, (LD ? I : 0)>{});
+    PP_BARRIER();
+    PP_WAIT_LGKM0();
+    mma(1);
+    PP_BARRIER();
+    // ---- phase 2: read B_2; issue I0 of K-tile J+2 (the A rows of this K-tile were read in phase 0); wait for I0, I1 of J+1
+    read_b(2);
+    if constexpr (RD2) res_read();
+    issue_i0(c2, par);
+    if constexpr (LD) PP_WAIT_VM(9);  // (the 4 residual pieces of phase 1 are younger than I2 of K-tile J+1)
+    else PP_WAIT_VM(5);
+    const bool last = kt + 1 == tile.ke;
+    PP_BARRIER();
+    PP_WAIT_LGKM0();
+    mma(2);
+    if constexpr (RD2) res_add(std::integral_constant<int, (RD2 ? I - 1 : 0)>{});
+    if (!last) PP_BARRIER();
+    c1 = c2;
+    pp_cursor_next<BM, BN>(g, walk, c2);
+    par ^= 1;
+    set_rd(par);
+    ++kt;
+  };
   for (int q = 0;; ++q) {
-    for (int kt = tile.kb; kt < tile.ke; ++kt) {
-      // ---- phase 0: read A, B_0; issue I1 of K-tile J+1; wait for I2 of this K-tile
-      read_a();
-      read_b(0);
-      issue_i1(c1, par ^ 1);
-      PP_WAIT_VM(5);
-      PP_BARRIER();
-      PP_WAIT_LGKM0();
-      mma(0);
-      PP_BARRIER();
-      // ---- phase 1: read B_1; issue I2 of K-tile J+1
-      read_b(1);
-      issue_i2(c1, par ^ 1);
-      PP_BARRIER();
-      PP_WAIT_LGKM0();
-      mma(1);
-      PP_BARRIER();
-      // ---- phase 2: read B_2; issue I0 of K-tile J+2 (the A rows of this K-tile were read in phase 0); wait for I0, I1 of J+1
-      read_b(2);
-      issue_i0(c2, par);
-      PP_WAIT_VM(5);
-      const bool last = kt + 1 == tile.ke;
-      PP_BARRIER();
-      PP_WAIT_LGKM0();
-      mma(2);
-      if (!last) PP_BARRIER();
-      c1 = c2;
-      pp_cursor_next<BM, BN>(g, walk, c2);
-      par ^= 1;
-      set_rd(par);
+    kt = tile.kb;
+    if constexpr (RP) {  // (a "+ residual" tile has >= 8 K-tiles and starts at K-tile 0: ctk_launch_gemm_pp; pp_sk_epi)
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
+      ktile(std::integral_constant<int, 2>{});
+      ktile(std::integral_constant<int, 3>{});
+      ktile(std::integral_constant<int, 4>{});
+      ktile(std::integral_constant<int, 5>{});
+      ktile(std::integral_constant<int, 6>{});
+      ktile(std::integral_constant<int, 7>{});
     }
+    while (kt < tile.ke) ktile(std::integral_constant<int, -1>{});
     if (grp == 0) PP_BARRIER();
     const PPTile done = tile;
     const bool more = pp_tile<BM, BN>(g, walk, q + 1, tile);
-    resid_issue();  // next tile's residual, requested before this tile's epilogue (see gemm_pp256_kernel)
-    pp_walk_epilogue<EPI, BM, BN, 2, 3>(g, walk, done, acc, lane, wave, w_unscale, bias_lds, lds + RING + PP_BIAS_BYTES + wave * 4096,
+    pp_walk_epilogue<EPI, BM, BN, 2, 3>(g, walk, done, acc, lane, wave, w_unscale, bias_lds, scr,
                                         [&](int mi) { return done.m0 + wm * 64 + mi * 32; }, [&](int ni) { return done.n0 + wn * 32 + ni * 64; }, (dbg & 2) != 0);
-    init_acc(w_scale);
+    init_acc();
     if (grp == 1) PP_BARRIER();
     if (!more) break;
   }
@@ -679,6 +758,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   if (tiles < cus) return -1;  // less than one tile per CU (virtual-track GEMMs, short streaming windows): the 64x64 / 128x128 kernels fill the chip better (tools/gemm_lab.cpp)
   const int wgs = (t_pp_cu_limit > 0 && t_pp_cu_limit < cus) ? t_pp_cu_limit : cus;  // (CtkPPCuLimit: leave CUs to concurrent small launches)
   const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
+  if (g.resid && g.K < 8 * 32) return -1;  // the residual rides on a tile's first eight K-tiles (gemm_pp192_kernel)
   if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
   if (!pp_epi_supported(code)) return -1;
   // ---- tail split: whole rounds here, the row blocks of a nearly empty last round as 64 x 64 tiles

@@ -17,8 +17,12 @@ __device__ __forceinline__ float ctk_half_sum(float v) {  // sum over the 32 lan
   return v;
 }
 
+// DUAL (round 5): a second, parameter-free normalisation of the same rows with its own eps goes to y2 from the same read --
+// the point tokens are normalised twice per depth from the same tokens (norm_context of the virtual<-points block,
+// cotracker.py:540/574, and norm1 of the points<-virtual block, :539/573); same arithmetic, same bits as two launches.
+template <bool DUAL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y, long R, const float* gamma,
-                                                         const float* beta, float eps, int out_split) {
+                                                         const float* beta, float eps, int out_split, float* y2, float eps2) {
   const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const int j = threadIdx.x & 31;
   if (row >= R) return;  // whole half-waves leave together (xor-shuffles stay inside a half)
@@ -37,31 +41,34 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, float* y
     q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
   }
   const float var = ctk_half_sum(q) * (1.0f / CTK_HID);
-  const float rstd = 1.0f / sqrtf(var + eps);
-  float* yr = y + row * CTK_HID + 4 * j;
-  _Float16* yh = reinterpret_cast<_Float16*>(y) + row * (2 * CTK_HID);  // SH row: 12 tiles x 64 halves
+  auto store = [&](float* yo, const float rstd, const float* ga, const float* be) {
+    float* yr = yo + row * CTK_HID + 4 * j;
+    _Float16* yh = reinterpret_cast<_Float16*>(yo) + row * (2 * CTK_HID);  // SH row: 12 tiles x 64 halves
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int c = 128 * k + 4 * j;
-    f32x4 o = v[k] * rstd;
-    if (gamma) o = o * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
-    if (out_split) {
-      // Whole lines: lanes j and j ^ 1 hold 8 consecutive columns; the even lane stores their 8 hi halves (own quad + the
-      // neighbour's), the odd lane their 8 lo halves -- 16 bytes each, and the 32 lanes of a row cover 512 consecutive bytes
-      // (4 SH lines) per instruction instead of eight 64-byte half-lines in two instructions (round 3, same bits).
-      f16x4 hi, lo;
-      ctk_split4(o, hi, lo);
-      const bool odd = j & 1;
-      const f32x2 give = __builtin_bit_cast(f32x2, odd ? hi : lo);
-      const f32x2 got = {__shfl_xor(give[0], 1, 64), __shfl_xor(give[1], 1, 64)};
-      const f16x4 theirs = __builtin_bit_cast(f16x4, got);
-      const f16x8 piece = odd ? ctk_cat8(theirs, lo) : ctk_cat8(hi, theirs);
-      _Float16* dst = yh + ctk_sh_col(c & ~7) + (odd ? 32 : 0);
-      *reinterpret_cast<f16x8*>(dst) = piece;
-    } else {
-      *reinterpret_cast<f32x4*>(yr + 128 * k) = o;
+    for (int k = 0; k < 3; ++k) {
+      const int c = 128 * k + 4 * j;
+      f32x4 o = v[k] * rstd;
+      if (ga) o = o * *reinterpret_cast<const f32x4*>(ga + c) + *reinterpret_cast<const f32x4*>(be + c);
+      if (out_split) {
+        // Whole lines: lanes j and j ^ 1 hold 8 consecutive columns; the even lane stores their 8 hi halves (own quad + the
+        // neighbour's), the odd lane their 8 lo halves -- 16 bytes each, and the 32 lanes of a row cover 512 consecutive bytes
+        // (4 SH lines) per instruction instead of eight 64-byte half-lines in two instructions (round 3, same bits).
+        f16x4 hi, lo;
+        ctk_split4(o, hi, lo);
+        const bool odd = j & 1;
+        const f32x2 give = __builtin_bit_cast(f32x2, odd ? hi : lo);
+        const f32x2 got = {__shfl_xor(give[0], 1, 64), __shfl_xor(give[1], 1, 64)};
+        const f16x4 theirs = __builtin_bit_cast(f16x4, got);
+        const f16x8 piece = odd ? ctk_cat8(theirs, lo) : ctk_cat8(hi, theirs);
+        _Float16* dst = yh + ctk_sh_col(c & ~7) + (odd ? 32 : 0);
+        *reinterpret_cast<f16x8*>(dst) = piece;
+      } else {
+        *reinterpret_cast<f32x4*>(yr + 128 * k) = o;
+      }
     }
-  }
+  };
+  store(y, 1.0f / sqrtf(var + eps), gamma, beta);
+  if (DUAL) store(y2, 1.0f / sqrtf(var + eps2), nullptr, nullptr);
 }
 
 // ---- token assembly: x[n*S+t][1024..1119] = [vis, conf, posenc(rel fwd/bwd coords), 0-pad] ---
@@ -187,8 +194,21 @@ extern "C" int ctk_layernorm(const float* x, void* y, int64_t R, const float* ga
   if (R <= 0) return CTK_E_SHAPE;
   if ((gamma == nullptr) != (beta == nullptr)) return CTK_E_NULL;
   CtkProfScope ps("layernorm", 8.0 * R * CTK_HID, 8.0 * R * CTK_HID, static_cast<hipStream_t>(stream));
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     static_cast<float*>(y), (long)R, gamma, beta, eps, out_split);
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     static_cast<float*>(y), (long)R, gamma, beta, eps, out_split, static_cast<float*>(nullptr), 0.0f);
+  CTK_HIP_CHECK_LAUNCH();
+  return CTK_OK;
+}
+
+// y = LayerNorm(x; gamma, beta, eps) and y2 = LayerNorm(x; no affine, eps2) from ONE read of x (api.hip: the point tokens of a depth)
+int ctk_launch_layernorm2(const float* x, void* y, long R, const float* gamma, const float* beta, float eps, void* y2, float eps2,
+                          int out_split, hipStream_t s) {
+  if (!x || !y || !y2) return CTK_E_NULL;
+  if (R <= 0) return CTK_E_SHAPE;
+  if ((gamma == nullptr) != (beta == nullptr)) return CTK_E_NULL;
+  CtkProfScope ps("layernorm", 12.0 * R * CTK_HID, 12.0 * R * CTK_HID, s);
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, s, x, static_cast<float*>(y), R, gamma, beta, eps,
+                     out_split, static_cast<float*>(y2), eps2);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }

@@ -1,4 +1,8 @@
-"""CNN feature encoder (stays on PyTorch-ROCm / MIOpen -- north_star keeps it out of the HIP path).
+"""CNN feature encoder: the parameter container and the PyTorch-ROCm / MIOpen forward (`model.encoder_backend = "torch"`).
+
+The DEFAULT back end since round 3 is `encoder_hip.py` (implicit-GEMM convolutions on SH NHWC activations, csrc/conv_pp.hip +
+encoder.hip: `model.encoder_backend = "hip"`); this module defines the layers -- so that reference checkpoints load into the
+same `fnet.*` keys -- and remains the selectable torch path and the reference the HIP encoder is tested against.
 
 Architecture of the reference ``BasicEncoder`` (cotracker/models/core/cotracker/blocks.py:141-219,
 residual unit :79-138) re-expressed with the same parameter names so that reference

@@ -231,8 +231,15 @@ def tail_aliases(prev, cur, dim, step):
         same = prev.untyped_storage().data_ptr() == cur.untyped_storage().data_ptr()
     except Exception:  # storage-less tensors
         return False
-    return bool(same and cur.storage_offset() == prev.storage_offset() + step * prev.stride(dim)
-                and getattr(prev, "_ctk_version", prev._version) == cur._version)
+    if not (same and cur.storage_offset() == prev.storage_offset() + step * prev.stride(dim)):
+        return False
+    # Tensors created under torch.inference_mode() do not track a version counter (reading `_version` raises): writes to them
+    # cannot be seen from the host, so the overlap cannot be PROVEN -> not an alias, the caller re-encodes (advisor, round 4).
+    try:
+        recorded = prev._ctk_version if hasattr(prev, "_ctk_version") else prev._version
+        return bool(recorded == cur._version)
+    except Exception:
+        return False
 
 
 class CoTrackerThreeBase(nn.Module):

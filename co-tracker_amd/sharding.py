@@ -26,6 +26,47 @@ def shard_queries(queries: torch.Tensor, world: int, rank: int) -> torch.Tensor:
     return queries[:, lo:hi]
 
 
+# Whether the process group's backend has the flat all-gather, decided ONCE per (backend, device type) on a 1-element tensor.
+# Every rank takes the probe at the same point of the same call, so it is itself a matched collective; what it catches is
+# "this backend does not implement the operator", and only that -- an error of a REAL collective (RCCL failure, timeout,
+# shape mismatch between ranks) propagates to the caller instead of being answered with a second, different collective that
+# the other ranks may never join (review of round 4).
+_FLAT_OK = {}
+
+
+def _flat_all_gather_ok(device: torch.device, group=None) -> bool:
+    backend = str(dist.get_backend(group))
+    key = (backend, device.type)
+    if key not in _FLAT_OK:
+        if backend == "nccl":  # ncclAllGather (RCCL): always there
+            _FLAT_OK[key] = True
+        else:
+            world = dist.get_world_size(group)
+            probe_in = torch.zeros(1, device=device)
+            probe_out = torch.zeros(world, device=device)
+            try:
+                dist.all_gather_into_tensor(probe_out, probe_in, group=group)
+                _FLAT_OK[key] = True
+            except NotImplementedError:
+                _FLAT_OK[key] = False
+            except RuntimeError as e:  # torch's "backend does not support ..." is a RuntimeError; anything else is a real failure
+                msg = str(e).lower()
+                if "not support" in msg or "not implemented" in msg or "unsupported" in msg:
+                    _FLAT_OK[key] = False
+                else:
+                    raise
+    return _FLAT_OK[key]
+
+
+def _gather_flat(full: torch.Tensor, mine: torch.Tensor, world: int, group=None) -> None:
+    """full [world * k, ...] <- every rank's mine [k, ...] in rank order, ONE collective; errors propagate."""
+    if _flat_all_gather_ok(mine.device, group):
+        dist.all_gather_into_tensor(full, mine, group=group)
+    else:  # per-rank VIEWS of the same preallocated buffer: still no list of fresh tensors, no cat
+        k = mine.shape[0]
+        dist.all_gather([full[r * k:(r + 1) * k] for r in range(world)], mine, group=group)
+
+
 def all_gather_tracks(tracks: torch.Tensor, vis: torch.Tensor, n_total: int, group=None, conf: torch.Tensor = None):
     """tracks [B,T,n_r,2], vis [B,T,n_r] (+ optionally conf [B,T,n_r]) of this rank -> ([B,T,N,2], [B,T,N](, [B,T,N])) on
     every rank.
@@ -34,7 +75,7 @@ def all_gather_tracks(tracks: torch.Tensor, vis: torch.Tensor, n_total: int, gro
     floats: x, y, visibility(, confidence)), `all_gather_into_tensor` (ncclAllGather under the "nccl" backend = RCCL; one hop
     per peer on the fully connected xGMI topology) fills a preallocated [world*per, B, T, C] buffer, and the results are
     permuted VIEWS of that buffer -- no list of per-rank tensors, no torch.cat, no second full-size copy (round 3 had both).
-    The returned tensors are therefore not contiguous; call .contiguous() if a consumer needs that.
+    The returned tensors are therefore NOT contiguous (`track_sharded`, the public entry point, returns contiguous ones).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
@@ -48,10 +89,7 @@ def all_gather_tracks(tracks: torch.Tensor, vis: torch.Tensor, n_total: int, gro
     if conf is not None:
         packed[:n_r, :, :, 3] = conf.to(torch.float32).permute(2, 0, 1)
     full = torch.empty(world * per, B, T, C, device=tracks.device, dtype=torch.float32)
-    try:
-        dist.all_gather_into_tensor(full, packed, group=group)
-    except (RuntimeError, NotImplementedError):  # a backend without the flat all-gather: per-rank VIEWS of the same buffer
-        dist.all_gather([full[r * per:(r + 1) * per] for r in range(world)], packed, group=group)
+    _gather_flat(full, packed, world, group)
     full = full[:n_total].permute(1, 2, 0, 3)  # [B,T,N,C] view
     vis_full = full[..., 2]
     if vis.dtype == torch.bool:
@@ -64,7 +102,8 @@ def track_sharded(predictor, video: torch.Tensor, queries: torch.Tensor, group=N
     """Track `queries` [B,N,3] with the points sharded over the ranks of `group`.
 
     `predictor` is any callable with CoTrackerPredictor.forward's signature.  Returns the full
-    ([B,T,N,2], [B,T,N]) on every rank.
+    ([B,T,N,2], [B,T,N]) on every rank, CONTIGUOUS like the predictor's own outputs (one 12-byte-per-point-frame copy of the
+    gathered buffer: 12.6 MB per rank at BASELINE configs[4]).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -75,7 +114,8 @@ def track_sharded(predictor, video: torch.Tensor, queries: torch.Tensor, group=N
         B, T = video.shape[:2]
         tracks = torch.zeros(B, T, 0, 2, device=video.device)
         vis = torch.zeros(B, T, 0, device=video.device, dtype=torch.bool)
-    return all_gather_tracks(tracks, vis, queries.shape[1], group)
+    tracks, vis = all_gather_tracks(tracks, vis, queries.shape[1], group)
+    return tracks.contiguous(), vis.contiguous()
 
 
 def dense_sharded(predictor, video: torch.Tensor, grid_query_frame: int = 0, grid_size: int = 80,
@@ -83,26 +123,28 @@ def dense_sharded(predictor, video: torch.Tensor, grid_query_frame: int = 0, gri
     """Dense mode (predictor.py:70-98) with its grid_step^2 independent point chunks dealt out over the ranks of
     `group`: the reference tracks the chunks one after another on one device and concatenates them; here rank r
     tracks chunks r, r+world, ... with the same per-chunk call (`predictor._dense_chunk`), and ONE fixed-size
-    all_gather per forward puts every chunk on every rank in the reference's chunk order.  Chunks all have the same
-    number of points, so no padding is needed except for ranks that run out of chunks."""
+    flat all-gather per forward (the same `all_gather_into_tensor` buffer scheme as `all_gather_tracks`: no list of
+    per-rank tensors, no torch.stack) puts every chunk on every rank.  Chunks all have the same number of points, so no
+    padding is needed except for ranks that run out of chunks."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_chunks, n_pts = predictor._dense_layout(video, grid_size)
     B, T = video.shape[:2]
     per = (n_chunks + world - 1) // world
-    mine = torch.zeros(B, T, per, n_pts, 3, device=video.device, dtype=torch.float32)
+    mine = torch.zeros(per, B, T, n_pts, 3, device=video.device, dtype=torch.float32)  # chunk-major: the gather's leading axis
     for j in range(per):
         c = rank + j * world   # round-robin: every rank has work until the chunks run out
         if c >= n_chunks:
             break
         tr, vi = predictor._dense_chunk(video, c, grid_query_frame, grid_size, backward_tracking)
-        mine[:, :, j, :, :2] = tr
-        mine[:, :, j, :, 2] = vi.to(torch.float32)
+        mine[j, :, :, :, :2] = tr
+        mine[j, :, :, :, 2] = vi.to(torch.float32)
     if world == 1:
-        full = mine
+        full = mine  # [per, B, T, n_pts, 3], chunk j == chunk id
     else:
-        out = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(out, mine, group=group)
-        full = torch.stack(out, dim=3).reshape(B, T, per * world, n_pts, 3)  # index j*world + r == chunk id
-    full = full[:, :, :n_chunks].reshape(B, T, n_chunks * n_pts, 3)
+        buf = torch.empty(world * per, B, T, n_pts, 3, device=video.device, dtype=torch.float32)
+        _gather_flat(buf, mine, world, group)
+        # buf[r * per + j] = chunk j * world + r: a VIEW in chunk-id order (the one copy is the .contiguous() below)
+        full = buf.view(world, per, B, T, n_pts, 3).permute(1, 0, 2, 3, 4, 5).reshape(per * world, B, T, n_pts, 3)
+    full = full[:n_chunks].permute(1, 2, 0, 3, 4).reshape(B, T, n_chunks * n_pts, 3)
     return full[..., :2].contiguous(), full[..., 2] > 0.5

@@ -590,7 +590,7 @@ def model_forward_online(fmaps, queries, p, window_len=16, iters=4, stride=4,
 # L3  CoTrackerThreeOffline.forward (post-encoder part)
 #                                        cotracker3_offline.py:104-233
 # --------------------------------------------------------------------------
-def model_forward_offline(fmaps, queries, p, iters=4, stride=4, model_resolution=(384, 512)):
+def model_forward_offline(fmaps, queries, p, iters=4, stride=4, model_resolution=(384, 512), add_space_attn=True):
     fmaps = np.asarray(fmaps, dtype=f32)
     queries = np.asarray(queries, dtype=f32)
     B, T = fmaps.shape[:2]
@@ -603,7 +603,7 @@ def model_forward_offline(fmaps, queries, p, iters=4, stride=4, model_resolution
     vis = np.zeros((B, T, N, 1), dtype=f32)
     conf = np.zeros((B, T, N, 1), dtype=f32)
     c, v, f = forward_window(pyr, coords, support, vis, conf, p, iters=iters,
-                             model_resolution=model_resolution, stride=stride)
+                             model_resolution=model_resolution, stride=stride, add_space_attn=add_space_attn)  # cotracker.py:496-502
     return (c * f32(stride)).astype(f32), sigmoid(v[..., 0]), sigmoid(f[..., 0])
 
 

@@ -161,3 +161,23 @@ def test_synthetic_inputs_are_deterministic():
     from cotracker_amd.synthetic import synthetic_video
     a, b = synthetic_video(3, 32, 48, seed=5), synthetic_video(3, 32, 48, seed=5)
     assert a.shape == (1, 3, 3, 32, 48) and torch.equal(a, b) and float(a.min()) >= 0 and float(a.max()) <= 255
+
+
+def test_tail_aliases_cannot_prove_overlap_for_inference_tensors():
+    """Streaming feature cache (model.online_feature_cache): the host-side overlap proof reads the autograd version counter.
+    Tensors allocated under torch.inference_mode() have none (`_version` raises): the proof must answer "not proven" -- the
+    chunk is then re-encoded -- instead of raising inside the predictor (advisor finding, round 4)."""
+    import torch
+
+    from cotracker_amd.model import tail_aliases
+
+    v = torch.zeros(1, 16, 3, 8, 8)
+    a = v[:, 0:8]
+    a._ctk_version = a._version
+    assert tail_aliases(a, v[:, 4:12], 1, 4)
+    v.add_(1.0)  # a write through a tensor sharing the version counter: stale
+    assert not tail_aliases(a, v[:, 4:12], 1, 4)
+    with torch.inference_mode():
+        w = torch.zeros(1, 16, 3, 8, 8)
+        assert tail_aliases(w[:, 0:8], w[:, 4:12], 1, 4) is False
+        assert tail_aliases(w[:, 0:8], w[:, 5:13], 1, 4) is False

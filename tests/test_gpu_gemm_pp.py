@@ -2,7 +2,10 @@
 
 Every Linear flavour of the update path, at sizes that take the persistent path (>= one 256-row tile per CU):
   * against fp64 (the nn.Linear contract) and against gemm_f16x3.hip's kernels (`ctk_gemm_pp_mode(0)`), which run the same
-    MFMA sequence per output element: bit-identical unless the residual is preloaded into the accumulators;
+    MFMA sequence per output element: bit-identical unless a residual is added (round 5: the residual tile rides on the
+    first eight K-tiles of a tile and is added into the accumulators between MFMA phases; gemm_f16x3.hip adds it last);
+  * with the TAIL SPLIT (mode bit 5, the default since round 5): the row blocks of a nearly empty last round go to the
+    64 x 64-tile kernel -- rows are independent, so the bits must not depend on where the cut is;
   * TIMING ROBUSTNESS: `ctk_gemm_pp_mode(9)` makes every wave sleep pseudo-random times around every barrier.  The LDS-DMA
     ring / barrier protocol must not depend on timing, so the result has to stay bit-identical.  (This is the test that
     found the round-3 race: a wave leaving its epilogue early issued LDS-DMA into a ring slot another wave of its group
@@ -20,7 +23,7 @@ CASES = {
     "to_kv": (256 * 90, 384, 768, ACT_NONE, False, False, False, True),                 # 256x256
     "corr_mlp.fc2": (256 * 260, 384, 256, ACT_NONE, False, True, False, True),          # 256x256, one column block
     "to_q": (256 * 130 + 31, 384, 384, ACT_NONE, False, False, False, True),            # 256x192, ragged M
-    "to_out": (256 * 131, 384, 384, ACT_NONE, True, False, False, True),                # 256x192, residual preload
+    "to_out": (256 * 131, 384, 384, ACT_NONE, True, False, False, True),                # 256x192, residual on the first 8 of 12 K-tiles
     "mlp.fc2": (256 * 129, 1536, 384, ACT_NONE, True, False, False, True),              # 256x192, long K
     "input_transform": (256 * 140, 1120, 384, ACT_NONE, False, False, True, False),     # 256x192, odd K-tile count (35), bias rows
     "corr_mlp.fc1": (256 * 128, 2432, 384, ACT_GELU_ERF, False, True, False, True),     # 256x192, erf GELU, SH output
@@ -40,7 +43,7 @@ def _run(case, mode, data):
             out = ops.gemm(a_sh, w, bias=b, act=act, bias_rows=br, packed=wp, out_split=split)
         torch.cuda.synchronize()
     finally:
-        _lib.load().ctk_gemm_pp_mode(1)
+        _lib.load().ctk_gemm_pp_mode(33)  # the library's default: persistent kernels + tail split
     return out
 
 
@@ -83,12 +86,22 @@ def test_gemm_pp_matches_fp64_old_kernels_and_survives_timing_jitter(case):
         assert torch.equal(_run(case, 1, data), new), "persistent kernel is not deterministic"
     for _ in range(3):
         assert torch.equal(_run(case, 9, data), new), "result depends on wave timing: LDS-DMA / barrier protocol race"
+    # tail split: the last row blocks run as 64 x 64 tiles with the same compile-time epilogue -- same bits, also under jitter;
+    # with a residual the persistent kernel adds it into the accumulators and the 64 x 64 kernel last: a rounding apart
+    split, split_jit = _run(case, 33, data), _run(case, 41, data)
+    assert torch.equal(split, split_jit), "tail split + timing jitter changed the result"
+    if res:
+        assert float((split.double() - ref).abs().max()) < tol
+        assert float((split - new).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
+    else:
+        assert torch.equal(split, new), "tail split changed the result"
 
 
 # Stream-K walk (ctk_gemm_pp_mode bit 4 + a lent scratch buffer, include/ctk.h: ctk_gemm_set_scratch): OFF by default --
 # measured gain 5 % on mlp.fc2 only, see gemm_pp.hip -- but it must stay correct: the two workgroups sharing a tile exchange
 # a partial tile through cache-bypassing stores / loads and per-wave flags.
-SK_CASES = ["to_q", "to_out", "mlp.fc2", "to_kv"]  # the linear f32 epilogues (the only ones that take part)
+SK_CASES = ["to_q", "to_kv"]  # the linear f32 epilogues without residual (the only ones that take part; round 5: a
+# "+ residual" tile must start at K-tile 0, where its residual rides on the first K-tiles -- the tail split covers those Linears)
 
 
 @pytest.mark.parametrize("case", SK_CASES)
@@ -133,6 +146,6 @@ def test_gemm_pp_stream_k_matches_rounds_is_deterministic_and_survives_jitter(ca
         assert torch.equal(_run(case, 1, data), rounds)  # bit 4 clear: the scratch is ignored
     finally:
         lib.ctk_gemm_set_scratch(None, 0, None)
-        lib.ctk_gemm_pp_mode(1)
+        lib.ctk_gemm_pp_mode(33)
     flags = scratch[:16384].view(torch.int32)
     assert int(flags.abs().max()) == 0, "a flag was left raised"

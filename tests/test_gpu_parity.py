@@ -812,10 +812,9 @@ def test_model_online_feature_cache(golden):
 
 def test_model_add_space_attn_false_matches_time_blocks_only(golden):
     """forward(add_space_attn=False) (cotracker.py:496-502) at MODEL level: the flag reaches the window driver
-    (ctk_window_args.flags), changes the result, is repeatable bit for bit and does not stick to the next call.  The NUMERIC
-    check of the time-blocks-only former against the numpy oracle (itself pinned on the imported reference,
-    tests/test_oracle_golden.py::test_update_former_add_space_attn_false_matches_reference) is the window-level
-    test_forward_window_vs_oracle_random above."""
+    (ctk_window_args.flags), changes the result, is repeatable bit for bit, does not stick to the next call, and (round 5)
+    equals the numpy oracle's offline forward run with the time-blocks-only former (itself pinned on the imported reference,
+    tests/test_oracle_golden.py::test_update_former_add_space_attn_false_matches_reference) within the north-star bars."""
     from cotracker_amd.model import CoTrackerThreeOffline
     from cotracker_amd.weights import fill_synthetic_
     g = golden("model_offline")
@@ -829,6 +828,19 @@ def test_model_add_space_attn_false_matches_time_blocks_only(golden):
     assert torch.isfinite(time_only).all() and torch.equal(time_only, again)
     assert maxdiff(full, time_only) > 1e-3          # the space blocks do something
     assert torch.equal(m(video, q, iters=2)[0], full)   # and the flag does not stick
+    # NUMERIC check at model level (round 5): the numpy oracle's whole offline forward with the time-blocks-only former
+    # (oracle.model_forward_offline(add_space_attn=False); its former is pinned on the imported reference), fed with the features
+    # this model's encoder produced -- coords 1e-3 px, logits 1e-4, the north-star bars
+    from oracle import cotracker_oracle as O  # checker only
+    c_t, v_t, f_t, _ = m(video, q, iters=2, add_space_attn=False)
+    fm = m._encode(video[0].float(), 8).permute(0, 3, 1, 2)[None].cpu().numpy()  # L2-normalised level-0 features [1,T,128,h,w]
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith("fnet.")}
+    oc, ov, of = O.model_forward_offline(fm, q.cpu().numpy(), p, iters=2, stride=4, model_resolution=(64, 96), add_space_attn=False)
+    assert maxdiff(c_t, oc) < 1e-3
+    assert maxdiff(logit(v_t), logit(torch.from_numpy(ov))) < 1e-4
+    assert maxdiff(logit(f_t), logit(torch.from_numpy(of))) < 1e-4
+    oc_full, _, _ = O.model_forward_offline(fm, q.cpu().numpy(), p, iters=2, stride=4, model_resolution=(64, 96))
+    assert maxdiff(full, oc_full) < 1e-3            # ... and the same harness reproduces the full former
 
 
 def test_constructor_variants_vis_conf_head_and_no_space_blocks(golden):

@@ -11,5 +11,5 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_pp_schedules_have_no_raw_or_war_hazard():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_pp_schedule.py")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    for name in ("pp256", "pp192", "conv_pp128"):
+    for name in ("pp256", "pp192", "conv_pp128", "pp192_resid"):
         assert f"{name}: OK" in out.stdout, out.stdout

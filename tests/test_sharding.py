@@ -135,3 +135,29 @@ def test_track_sharded_two_ranks_on_gpu_equals_sequential_chunks():
             assert err == 0.0 and flips == 0, out[r]
             assert dshape == (1, 8, 4 * 80 * 48, 2)
             assert derr == 0.0 and dflips == 0, out[r]
+
+
+# ---- RCCL, two real devices (round 5): collected everywhere, runs only where a second GPU exists ------------------------------
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_track_sharded_nccl_world2():
+    """BASELINE configs[4] on two real devices: `bench.py --gpus 2 --workload c5_shard` launches one rank per GPU under
+    torch.distributed.run with the "nccl" backend (= RCCL), rank r tracks chunk r of the 265 x 265 grid, ONE
+    all_gather_into_tensor returns the tracks; rank 0's timed chunk is checked against the reference's CPU run of chunk 0
+    (tests/golden: scale_c5_chunk0) inside the bench line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c5_shard", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extra-lines", "--no-profile"], capture_output=True, text=True, env=env, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dist_backend"] == "nccl"
+    devs = {(d["device"], d["device_index"]) for d in line["rank_devices"]}
+    assert len(devs) == 2, line["rank_devices"]
+    par = line["parity"]["timed_step"]
+    assert par["coords_px"] <= 1e-3 and par["vis_logit"] <= 1e-4 and par["conf_logit"] <= 1e-4, par  # north_star's bars
+    assert line["all_gather_ms"] is not None

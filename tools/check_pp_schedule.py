@@ -8,7 +8,12 @@ Intervals: group G runs the load segment of phase g in interval 2g+G and its MFM
 import itertools
 
 
-def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=3):
+def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=3, extra=None, stores_per_tile=0):
+    """extra (round 5, the "+ residual" Linears of gemm_pp192_kernel): extra(i, p) -> (n_loads, wait_override, needs_landed) for
+    phase p of the i-th K-tile of a tile: n_loads ordinary loads issued BEHIND the phase's DMA block (they sit in the same
+    in-order vmcnt queue), an optional vmcnt value replacing the program's, and the (tile, i) whose loads this phase consumes
+    (they must have been retired by a wait of an EARLIER phase of the same wave).  stores_per_tile: the epilogue's stores,
+    which queue behind the DMA pieces issued before them (gfx9 has no vscnt)."""
     """program[p] = (reads, issue, wait) for phase p of K-tile J:
          reads : list of block kinds read from K-tile J in this phase
          issue : (dJ, kind, pieces_per_wave) or None -- block of K-tile J+dJ issued in this phase
@@ -29,6 +34,8 @@ def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=
         done_upto = len(issued)
         for i in range(len(issued) - 1, -1, -1):
             if left - issued[i][2] < 0:
+                if left > 0:
+                    done_upto = i  # some pieces of this block may still be in flight: the block is NOT complete
                 break
             left -= issued[i][2]
             done_upto = i
@@ -38,8 +45,16 @@ def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=
     apply_wait(prologue[1], -1)
     g = 0
     for J in range(total_kt):
+        if extra is not None and stores_per_tile and J > 0 and J % KT == 0:
+            issued.append((("S", J // KT), "S", stores_per_tile, g))  # the finished tile's stores
         for p in range(phases_per_kt):
             reads, issue, wait = program[p]
+            n_extra, wait_override, needs = extra(J % KT, p) if extra is not None else (0, None, None)
+            if wait_override is not None:
+                wait = wait_override
+            if needs is not None:
+                key = (("R", J // KT, needs), "R")
+                assert key in waited_until and waited_until[key] < g, f"{name}: residual loads {key} consumed in phase {g} before a wait retired them"
             for kind in reads:
                 key = (J, kind)
                 assert key in waited_until, f"{name}: phase {g} reads {key} which no wait covers"
@@ -60,6 +75,8 @@ def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=
                         assert (Jslot - ring_kt, ko) in last_read, f"{name}: {(Jslot, kind)} overwrites unread {(Jslot - ring_kt, ko)} at phase {g}"
                 issued.append((Jslot if Jslot < total_kt else -Jslot, kind, n, g))
                 issue_phase[(Jslot, kind)] = g
+            if n_extra:
+                issued.append((("R", J // KT, J % KT), "R", n_extra, g))
             if wait is not None:
                 apply_wait(wait, g)
             g += 1
@@ -88,3 +105,18 @@ check("conv_pp128", 2,
       ([(0, "I0", 3), (0, "I1", 3), (1, "I0", 3), (1, "I1", 3)], 6),
       [(["I0", "I1"], (2, "I0", 3), None), (["I1"], (2, "I1", 3), 6)],
       slot_of=lambda k: {"I0": 1, "I1": 2}[k], ring_kt=3)
+
+# ---- 256 x 192 with the residual riding on a tile's first eight K-tiles (gemm_pp192_kernel, EPI bit 2): K-tile i < 6 requests the
+# four line pieces of sub-tile i in phase 1 (behind I2) and its phase-2 wait is vmcnt(9); K-tile i + 1 consumes them in phase 1.
+def _resid(i, p):
+    n = 4 if (p == 1 and i <= 5) else 0
+    w = 9 if (p == 2 and i <= 5) else None
+    needs = (i - 1) if (p == 1 and 1 <= i <= 6) else None
+    return n, w, needs
+
+
+all_kinds = ["I0", "I1", "I2"]
+check("pp192_resid", 3,
+      ([(0, "I0", 3), (0, "I1", 2), (0, "I2", 2), (1, "I0", 3)], 5),
+      [(["I0", "I1"], (1, "I1", 2), 5), (["I2"], (1, "I2", 2), None), (["I2"], (2, "I0", 3), 5)],
+      slot_of=lambda k: {"I0": 1, "I1": 2, "I2": 4}[k], ring_kt=2, KT=12, tiles=3, extra=_resid, stores_per_tile=24)

@@ -111,6 +111,12 @@ def main():
     import os
     so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "co-tracker_amd", "libctk_hip.so")
     keep["_lib_sha256"] = hashlib.sha256(open(so, "rb").read()).hexdigest() if os.path.exists(so) else None
+    # ... and the hash of the kernel SOURCES (round 5): the same on every box, so the driver's run recognises the file even if its
+    # toolchain produced different bytes; either stamp matching makes the file fresh for bench.py
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as _ge
+    keep["_src_sha256"] = _ge.source_hash()
     json.dump(keep, open(out, "w"), indent=1)  # library kernels only (others are printed)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:28s} n={v['dispatches']:6d}  fetch {v['fetch_bytes_per_launch'] or 0:14.0f} B  write {v['write_bytes_per_launch'] or 0:14.0f} B")
