@@ -25,6 +25,35 @@
 
 namespace {
 
+// ---- wave timeline (DBG kernels only, ctk_gemm_pp_mode bit 6): the first PP_TRACE_WGS workgroups stamp s_memtime at the start of
+// every MFMA phase (right behind the lgkmcnt(0) wait that is there anyway), before and after every epilogue, into the 8 KiB of LDS
+// no kernel uses, and dump them at exit; ctk_debug_pp_trace() copies them out (tools/gemm_lab trace).  The stamp itself waits
+// for its SMEM result (~100 cycles per phase): periods are inflated uniformly, their RATIOS are what is read.
+constexpr int PP_TRACE_WGS = 4, PP_TRACE_STAMPS = 128, PP_TRACE_OFF = 155648;
+__device__ unsigned long long g_pp_trace[PP_TRACE_WGS * 8 * PP_TRACE_STAMPS];
+#define PP_STAMP()                                                                                                      \
+  do {                                                                                                                  \
+    if (DBG && tr_on) {                                                                                                 \
+      unsigned long long t_;                                                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");                                     \
+      if (lane == 0 && tr_n < PP_TRACE_STAMPS) *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + tr_n * 8) = t_; \
+      ++tr_n;                                                                                                           \
+    }                                                                                                                   \
+  } while (0)
+#define PP_TRACE_INIT()                                                                                                 \
+  const bool tr_on = DBG && (dbg & 64) != 0 && blockIdx.x < PP_TRACE_WGS;                                               \
+  int tr_n = 0;                                                                                                         \
+  if (DBG && tr_on) {                                                                                                   \
+    for (int i = lane; i < PP_TRACE_STAMPS; i += 64) *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + i * 8) = 0ull; \
+  }
+#define PP_TRACE_DUMP()                                                                                                 \
+  do {                                                                                                                  \
+    if (DBG && tr_on) {                                                                                                 \
+      for (int i = lane; i < PP_TRACE_STAMPS; i += 64)                                                                  \
+        g_pp_trace[((long)blockIdx.x * 8 + wave) * PP_TRACE_STAMPS + i] = *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + i * 8); \
+    }                                                                                                                   \
+  } while (0)
+
 // ---- tile walk -----------------------------------------------------------------------------------
 // Two ways to deal the tiles to the G persistent workgroups:
 //  * rounds (no scratch memory): in round r the G (or fewer) tiles [r*G, r*G + n_r) are dealt so that XCD x (workgroup b sits
@@ -227,6 +256,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
   const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
   pp_stage_bias<EPI>(g, lds + RING, tid);
+  PP_TRACE_INIT();
   if (dbg >> 8) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
     const int n = ((blockIdx.x >> 3) & 3) * (dbg >> 8);
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
@@ -342,6 +372,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
       PP_WAIT_VM(8);
       PP_BARRIER();
       PP_WAIT_LGKM0();
+      PP_STAMP();
       mma(0, 0);
       PP_BARRIER();
       // ---- phase 1 (a=0, b=1): read B_1; issue A_1 of K-tile J+1
@@ -350,6 +381,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
       PP_WAIT_VM(8);
       PP_BARRIER();
       PP_WAIT_LGKM0();
+      PP_STAMP();
       mma(0, 1);
       PP_BARRIER();
       // ---- phase 2 (a=1, b=1): read A_1; issue A_0 of K-tile J+2 (into the slot A_0 of this K-tile left in phase 0)
@@ -358,6 +390,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
       PP_WAIT_VM(8);
       PP_BARRIER();
       PP_WAIT_LGKM0();
+      PP_STAMP();
       mma(1, 1);
       PP_BARRIER();
       // ---- phase 3 (a=1, b=0): nothing to read (B_0 is still in registers); issue B_0 of K-tile J+2
@@ -365,6 +398,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
       PP_WAIT_VM(8);
       const bool last = kt + 1 == tile.ke;
       PP_BARRIER();
+      PP_STAMP();
       mma(1, 0);
       if (!last) PP_BARRIER();
       // advance the stream
@@ -382,6 +416,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
     // ---- epilogue: group 0 after the phase's closing barrier, group 1 before it -- both write their tile at the same
     // time (one MFMA phase apart) and the stagger survives into the next tile
     if (grp == 0) PP_BARRIER();
+    PP_STAMP();  // epilogue begins
     // the next tile's residual is requested BEFORE this tile's epilogue (it lands behind the epilogue's arithmetic and stores);
     // the epilogue therefore works on a copy of the tile descriptor
     const PPTile done = tile;
@@ -391,11 +426,13 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
                                         [&](int i) { return done.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; }, [&](int b) { return done.n0 + wn * 32 + b * 128; },
                                         (dbg & 2) != 0);
     init_acc(w_scale);
+    PP_STAMP();  // epilogue done
     if (grp == 1) PP_BARRIER();
     if (!more) break;
   }
   if (grp == 0) PP_BARRIER();  // balance group 1's extra barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // duplicate tail blocks may still be landing
+  PP_TRACE_DUMP();
 }
 
 // ================================================================================================
@@ -430,6 +467,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
   const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
   pp_stage_bias<EPI>(g, lds + RING, tid);
+  PP_TRACE_INIT();
   if (dbg >> 8) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
     const int n = ((blockIdx.x >> 3) & 3) * (dbg >> 8);
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
@@ -603,6 +641,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     PP_WAIT_VM(5);
     PP_BARRIER();
     PP_WAIT_LGKM0();
+    PP_STAMP();
     mma(0);
     if constexpr (RD0) res_add(std::integral_constant<int, (RD0 ? I - 2 : 0)>{});
     PP_BARRIER();
@@ -613,6 +652,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     if constexpr (LD) res_load(std::integral_constant<int, (LD ? I : 0)>{});
     PP_BARRIER();
     PP_WAIT_LGKM0();
+    PP_STAMP();
     mma(1);
     PP_BARRIER();
     // ---- phase 2: read B_2; issue I0 of K-tile J+2 (the A rows of this K-tile were read in phase 0); wait for I0, I1 of J+1
@@ -624,6 +664,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     const bool last = kt + 1 == tile.ke;
     PP_BARRIER();
     PP_WAIT_LGKM0();
+    PP_STAMP();
     mma(2);
     if constexpr (RD2) res_add(std::integral_constant<int, (RD2 ? I - 1 : 0)>{});
     if (!last) PP_BARRIER();
@@ -647,16 +688,19 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     }
     while (kt < tile.ke) ktile(std::integral_constant<int, -1>{});
     if (grp == 0) PP_BARRIER();
+    PP_STAMP();  // epilogue begins
     const PPTile done = tile;
     const bool more = pp_tile<BM, BN>(g, walk, q + 1, tile);
     pp_walk_epilogue<EPI, BM, BN, 2, 3>(g, walk, done, acc, lane, wave, w_unscale, bias_lds, scr,
                                         [&](int mi) { return done.m0 + wm * 64 + mi * 32; }, [&](int ni) { return done.n0 + wn * 32 + ni * 64; }, (dbg & 2) != 0);
     init_acc();
+    PP_STAMP();  // epilogue done
     if (grp == 1) PP_BARRIER();
     if (!more) break;
   }
   if (grp == 0) PP_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_TRACE_DUMP();
 }
 
 thread_local int t_pp_cu_limit = 0;
@@ -702,6 +746,14 @@ CtkPPScratchScope::~CtkPPScratchScope() {
 }
 
 extern "C" void ctk_gemm_pp_mode(int mode) { g_pp_mode = mode; }
+
+// dev tool (tools/gemm_lab trace; not part of include/ctk.h): the wave timeline the last DBG launch with mode bit 6 recorded,
+// [PP_TRACE_WGS workgroups][8 waves][PP_TRACE_STAMPS] s_memtime values (0 = not written)
+extern "C" int ctk_debug_pp_trace(unsigned long long* host_out, int n) {
+  if (!host_out || n <= 0 || n > PP_TRACE_WGS * 8 * PP_TRACE_STAMPS) return CTK_E_SHAPE;
+  const hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_trace), (size_t)n * 8);
+  return e == hipSuccess ? CTK_OK : (int)e;
+}
 
 extern "C" int ctk_gemm_scratch_bytes(size_t* out_bytes) {
   if (!out_bytes) return CTK_E_NULL;
@@ -791,7 +843,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   CtkProfScope ps(pname, flops * frac, bytes * frac, s);
   // stream-K only on the stream whose entry point lent the scratch (one persistent GEMM at a time uses the slots)
   g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;
-  const bool dbgk = (g_pp_mode & ~(17 | 32)) != 0;
+  const bool dbgk = (g_pp_mode & ~(17 | 32)) != 0;  // (bit 6 = wave timeline: DBG kernels)
 #define PP_CASE(E)                                                                                             \
   case E:                                                                                                      \
     if (t256 && dbgk) hipLaunchKernelGGL((gemm_pp256_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);   \

@@ -9,8 +9,8 @@ import itertools
 
 
 def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=3, extra=None, stores_per_tile=0):
-    """extra (round 5, the "+ residual" Linears of gemm_pp192_kernel): extra(i, p) -> (n_loads, wait_override, needs_landed) for
-    phase p of the i-th K-tile of a tile: n_loads ordinary loads issued BEHIND the phase's DMA block (they sit in the same
+    """extra (round 5): extra(i, p, tile) -> (n_loads, wait_override, needs_landed) for phase p of the i-th K-tile of tile `tile`
+    of the workgroup's walk: n_loads ordinary loads issued BEHIND the phase's DMA block (they sit in the same
     in-order vmcnt queue), an optional vmcnt value replacing the program's, and the (tile, i) whose loads this phase consumes
     (they must have been retired by a wait of an EARLIER phase of the same wave).  stores_per_tile: the epilogue's stores,
     which queue behind the DMA pieces issued before them (gfx9 has no vscnt)."""
@@ -49,7 +49,7 @@ def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=
             issued.append((("S", J // KT), "S", stores_per_tile, g))  # the finished tile's stores
         for p in range(phases_per_kt):
             reads, issue, wait = program[p]
-            n_extra, wait_override, needs = extra(J % KT, p) if extra is not None else (0, None, None)
+            n_extra, wait_override, needs = extra(J % KT, p, J // KT) if extra is not None else (0, None, None)
             if wait_override is not None:
                 wait = wait_override
             if needs is not None:
@@ -108,7 +108,7 @@ check("conv_pp128", 2,
 
 # ---- 256 x 192 with the residual riding on a tile's first eight K-tiles (gemm_pp192_kernel, EPI bit 2): K-tile i < 6 requests the
 # four line pieces of sub-tile i in phase 1 (behind I2) and its phase-2 wait is vmcnt(9); K-tile i + 1 consumes them in phase 1.
-def _resid(i, p):
+def _resid(i, p, tile):
     n = 4 if (p == 1 and i <= 5) else 0
     w = 9 if (p == 2 and i <= 5) else None
     needs = (i - 1) if (p == 1 and 1 <= i <= 6) else None

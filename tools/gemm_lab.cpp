@@ -34,6 +34,8 @@
     }                                                                               \
   } while (0)
 
+extern "C" int ctk_debug_pp_trace(unsigned long long* host_out, int n);  // gemm_pp.hip dev entry (not in ctk.h)
+
 struct Shape {
   const char* name;
   long M;
@@ -120,6 +122,7 @@ int main(int argc, char** argv) {
     shapes.push_back({"kv  ragged M  ", 102400 - 200, 384, 768, CTK_ACT_NONE, false, false, false, true, 1});
   }
 
+  if (argc > 1 && !strcmp(argv[1], "trace") && shapes.size() > 6) shapes.resize(6);
   std::mt19937 rng(1234);
   std::normal_distribution<float> nd(0.f, 1.f);
   int failures = 0;
@@ -216,6 +219,46 @@ int main(int argc, char** argv) {
       return ms / reps;
     };
 
+    if (argc > 1 && !strcmp(argv[1], "trace")) {
+      // wave timeline of the DBG kernel (mode bit 6): s_memtime at the start of every MFMA phase + around every epilogue
+      time_mode(dC1, 1);  // warm caches and clocks on the production kernel
+      run(dC1, 65);
+      HIP_OK(hipStreamSynchronize(st));
+      const int WGS = 4, ST = 128;
+      std::vector<unsigned long long> tr((size_t)WGS * 8 * ST);
+      CTK_OKAY(ctk_debug_pp_trace(tr.data(), (int)tr.size()));
+      const bool t256 = (N % 256) == 0;
+      const int ph = t256 ? 4 : 3, KT = K / 32, per_tile = ph * KT + 2;
+      printf("%s M=%ld K=%d N=%d: %d phases/K-tile, %d K-tiles, %d stamps per tile (cycles of s_memtime)\n", sh.name, M, K, N, ph, KT, per_tile);
+      for (int wg = 0; wg < 2; ++wg)
+        for (int wv : {0, 3, 4, 7}) {
+          const unsigned long long* t = &tr[((size_t)wg * 8 + wv) * ST];
+          int n = 0;
+          while (n < ST && t[n]) ++n;
+          printf("  wg %d wave %d: %d stamps;", wg, wv, n);
+          for (int tile = 0; tile * per_tile + per_tile <= n; ++tile) {
+            const unsigned long long* b = t + tile * per_tile;
+            // phase-to-phase periods by phase index, first K-tile apart
+            double sum[4] = {0, 0, 0, 0};
+            int cnt[4] = {0, 0, 0, 0};
+            for (int i = ph; i + 1 < ph * KT; ++i) {  // skip the first K-tile
+              sum[i % ph] += (double)(b[i + 1] - b[i]);
+              cnt[i % ph]++;
+            }
+            printf(" | tile %d: first K-tile %llu, period by phase", tile, b[ph] - b[0]);
+            for (int p = 0; p < ph; ++p) printf(" %.0f", cnt[p] ? sum[p] / cnt[p] : 0.0);
+            printf(", main loop %llu, last phase->epi %llu, epilogue %llu", b[ph * KT - 1] - b[0], b[ph * KT] - b[ph * KT - 1], b[ph * KT + 1] - b[ph * KT]);
+            if (tile * per_tile + per_tile < n) printf(", epi end->next phase 0 %llu", b[per_tile] - b[ph * KT + 1]);
+          }
+          printf("\n");
+        }
+      fflush(stdout);
+      HIP_OK(hipFree(dA)); HIP_OK(hipFree(dAsh)); HIP_OK(hipFree(dW)); HIP_OK(hipFree(dC0)); HIP_OK(hipFree(dC1)); HIP_OK(hipFree(dC2));
+      HIP_OK(hipFree(dWp));
+      if (db) HIP_OK(hipFree(db));
+      if (dbr) HIP_OK(hipFree(dbr));
+      continue;
+    }
     if (exp_mode) {
       printf("%s M=%7ld K=%4d N=%4d B=%d |", sh.name, M, K, N, B);
       std::vector<double> best(exp_modes.size(), 1e30);
