@@ -196,6 +196,8 @@ constexpr int QT_PER_WG = 4;        // 128-query tiles per workgroup of attentio
 // a line it shares with its neighbour head (16 hi halves = 32 bytes, 16 lo halves = 32 bytes).  The job's output goes
 // through a wave-private LDS image -- [32 rows][full line 128 B | hi part 32 B | lo part 32 B], pitch 208 B -- and
 // leaves as 6 instructions whose lanes (row, 16-byte chunk) cover a row's 192 bytes in order.  Same values, same bits.
+constexpr int VT_PITCH = 52;                       // floats per key / token slot of the V transpose images (attention_q64_kernel, attention_time16_kernel)
+constexpr int VT_BYTES = 32 * VT_PITCH * 4;        // 6656 B per wave
 constexpr int OIMG_PITCH = 208;
 constexpr int OIMG_BYTES = 32 * OIMG_PITCH;  // 6656 per wave
 
@@ -408,25 +410,23 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
   const long kstride = p.kv_is * p.kv_ld;
   const int vd0 = r32, vd1 = min(32 + r32, HD - 1);  // dims of my V^T rows (rows 48..63 of the 2nd tile: unused outputs)
 
-  f32x4 kraw[6];
-  float vraw[2][16];
+  // Round 5: the V rows of a tile travel like its K rows (6 row-contiguous 16-byte loads per lane instead of 32 scalar loads) and
+  // are transposed into the V^T operand order through a wave-private LDS image that borrows this wave's slice of `red` (written
+  // only after the key loop): 12 memory instructions per 32-key tile instead of 38.  Same values, same bits.
+  f32x4 kraw[6], vrow[6];
+  float* vt = &red[wave][0][0];  // [32 keys][VT_PITCH floats] = 6656 B of this wave's 12800
   auto load_tile = [&](int tile) {
     const int k0 = kbeg + tile * 32;
-    const float* kp = kbase + (long)min(k0 + r32, kend - 1) * kstride;
+    const long row = (long)min(k0 + r32, kend - 1) * kstride;
+    const float* kp = kbase + row;
+    const float* vp = vbase + row + half * 8;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       kraw[2 * j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
       kraw[2 * j + 1] = *reinterpret_cast<const f32x4*>(kp + 16 * j + 4);
+      vrow[2 * j] = *reinterpret_cast<const f32x4*>(vp + 16 * j);
+      vrow[2 * j + 1] = *reinterpret_cast<const f32x4*>(vp + 16 * j + 4);
     }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int key = min(k0 + 16 * s + 8 * (e >> 2) + 4 * half + (e & 3), kend - 1);
-        const float* vp = vbase + (long)key * kstride;
-        vraw[0][s * 8 + e] = vp[vd0];
-        vraw[1][s * 8 + e] = vp[vd1];
-      }
   };
 
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
@@ -444,14 +444,33 @@ __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
     f16x8 kh[3], kl[3], vh[2][2], vl[2][2];  // V: [dim tile][k-step]
 #pragma unroll
     for (int j = 0; j < 3; ++j) ctk_split8(kraw[2 * j], kraw[2 * j + 1], kh[j], kl[j]);
+    {  // V rows -> LDS image -> V^T fragments: element (k-step s, e) of lane (dim, half) = V[key 16 s + 8 (e >> 2) + 4 half + (e & 3)][dim]
+      float* wrow = vt + r32 * VT_PITCH + half * 8;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const f32x4 a = {vraw[dt][s * 8], vraw[dt][s * 8 + 1], vraw[dt][s * 8 + 2], vraw[dt][s * 8 + 3]};
-        const f32x4 c = {vraw[dt][s * 8 + 4], vraw[dt][s * 8 + 5], vraw[dt][s * 8 + 6], vraw[dt][s * 8 + 7]};
-        ctk_split8(a, c, vh[dt][s], vl[dt][s]);
+      for (int j = 0; j < 3; ++j) {
+        *reinterpret_cast<f32x4*>(wrow + 16 * j) = vrow[2 * j];
+        *reinterpret_cast<f32x4*>(wrow + 16 * j + 4) = vrow[2 * j + 1];
       }
+      __builtin_amdgcn_wave_barrier();  // (one wave, in-order LDS: the reads below see every lane's writes)
+      float vraw[2][16];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = 16 * s + 8 * (e >> 2) + 4 * half + (e & 3);
+          vraw[0][s * 8 + e] = vt[key * VT_PITCH + vd0];
+          vraw[1][s * 8 + e] = vt[key * VT_PITCH + vd1];
+        }
+      __builtin_amdgcn_wave_barrier();  // (the next tile's writes stay behind these reads)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const f32x4 a = {vraw[dt][s * 8], vraw[dt][s * 8 + 1], vraw[dt][s * 8 + 2], vraw[dt][s * 8 + 3]};
+          const f32x4 c = {vraw[dt][s * 8 + 4], vraw[dt][s * 8 + 5], vraw[dt][s * 8 + 6], vraw[dt][s * 8 + 7]};
+          ctk_split8(a, c, vh[dt][s], vl[dt][s]);
+        }
+    }
     if (tile + 4 < ntiles) load_tile(tile + 4);  // raw registers are free again: prefetch behind the MFMAs
 
     f32x16 sacc[2];
@@ -720,15 +739,20 @@ __global__ __launch_bounds__(256, 2) void attention_self_kernel(AttnP p) {
 // multiplies the current one, so the memory latency of job i+1 hides behind the arithmetic of job i.  Jobs are numbered
 // head-fastest: neighbouring waves read neighbouring 192-byte head slices of the same token rows.  The arithmetic (split,
 // MFMA order, log2-domain softmax) is that of attention_self_kernel<2>, instruction for instruction: same bits out.
+// Round 5: the V rows travel like the K rows -- 6 row-contiguous 16-byte loads per lane -- and are transposed into the V^T
+// operand order through a wave-private LDS image ([32 token slots][52 floats]: conflict-free 16-byte writes, the 32 column
+// reads of a lane hit 32 consecutive banks).  Until round 4 every lane fetched its 32 V^T elements with 32 scalar
+// global_load_dword: 44 memory instructions per job, and the request stream, not the DRAM pins, bounded the kernel
+// (profiles/r04_sq_counters.txt: 65 % of a wave's life waiting for operands at 4.0 TB/s).  Now 18.  Same values, same bits.
 struct TimeRaw {
-  f32x4 q[6], k[6];
-  float v0[16], v1[16];
+  f32x4 q[6], k[6], v[6];
 };
 
 __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long njobs) {
-  __shared__ __attribute__((aligned(16))) unsigned char oimg_all[4 * OIMG_BYTES];  // SH output images (attn_store_sh_head), one per wave
+  __shared__ __attribute__((aligned(16))) unsigned char oimg_all[4 * (OIMG_BYTES + VT_BYTES)];  // per wave: SH output image (attn_store_sh_head) | V transpose image
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r32 = lane & 31, half = lane >> 5;
-  unsigned char* oimg = oimg_all + wave * OIMG_BYTES;
+  unsigned char* oimg = oimg_all + wave * (OIMG_BYTES + VT_BYTES);
+  float* vt = reinterpret_cast<float*>(oimg + OIMG_BYTES);
   const long stride = (long)gridDim.x * 4;
   long job = (long)blockIdx.x * 4 + wave;
   if (job >= njobs) return;  // wave-uniform
@@ -740,24 +764,19 @@ __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long 
     const int b0 = (int)(jb / CTK_HEADS) * 2;
     const int bc = min(b0 + rb, p.nbatch - 1), ic = min(ri, p.n1 - 1);
     const float* qp = p.q + ((long)bc * p.q_bs + (long)ic * p.q_is) * p.q_ld + head * HD + half * 8;
-    const float* kp = p.k + ((long)bc * p.kv_bs + (long)ic * p.kv_is) * p.kv_ld + head * HD + half * 8;
+    // (n1 == n2 here: my query row, my key row and my value row are the same token slot r32 = 16 * batch + frame)
+    const long krow = ((long)bc * p.kv_bs + (long)min(ri, p.n2 - 1) * p.kv_is) * p.kv_ld + head * HD + half * 8;
+    const float* kp = p.k + krow;
+    const float* vp = p.v + krow;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       r.q[2 * j] = *reinterpret_cast<const f32x4*>(qp + 16 * j);
       r.q[2 * j + 1] = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4);
       r.k[2 * j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
       r.k[2 * j + 1] = *reinterpret_cast<const f32x4*>(kp + 16 * j + 4);
+      r.v[2 * j] = *reinterpret_cast<const f32x4*>(vp + 16 * j);
+      r.v[2 * j + 1] = *reinterpret_cast<const f32x4*>(vp + 16 * j + 4);
     }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int slot = 16 * s + 8 * (e >> 2) + 4 * half + (e & 3);
-        const int kb = min(b0 + (slot >> 4), p.nbatch - 1), ki = min(slot & 15, p.n2 - 1);
-        const float* vp = p.v + ((long)kb * p.kv_bs + (long)ki * p.kv_is) * p.kv_ld + head * HD;
-        r.v0[8 * s + e] = vp[vd0];
-        r.v1[8 * s + e] = vp[vd1];
-      }
   };
 
   TimeRaw raw;
@@ -772,12 +791,31 @@ __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long 
       ctk_split8(raw.q[2 * j] * p.scale2, raw.q[2 * j + 1] * p.scale2, qh[j], ql[j]);
       ctk_split8(raw.k[2 * j], raw.k[2 * j + 1], kh[j], kl[j]);
     }
+    {  // V rows -> LDS image -> V^T fragments: element (k-step s, e) of lane (dim, half) = V[slot 16 s + 8 (e >> 2) + 4 half + (e & 3)][dim]
+      float* wrow = vt + r32 * VT_PITCH + half * 8;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      ctk_split8(f32x4{raw.v0[8 * s], raw.v0[8 * s + 1], raw.v0[8 * s + 2], raw.v0[8 * s + 3]},
-                 f32x4{raw.v0[8 * s + 4], raw.v0[8 * s + 5], raw.v0[8 * s + 6], raw.v0[8 * s + 7]}, vh[0][s], vl[0][s]);
-      ctk_split8(f32x4{raw.v1[8 * s], raw.v1[8 * s + 1], raw.v1[8 * s + 2], raw.v1[8 * s + 3]},
-                 f32x4{raw.v1[8 * s + 4], raw.v1[8 * s + 5], raw.v1[8 * s + 6], raw.v1[8 * s + 7]}, vh[1][s], vl[1][s]);
+      for (int j = 0; j < 3; ++j) {
+        *reinterpret_cast<f32x4*>(wrow + 16 * j) = raw.v[2 * j];
+        *reinterpret_cast<f32x4*>(wrow + 16 * j + 4) = raw.v[2 * j + 1];
+      }
+      __builtin_amdgcn_wave_barrier();  // (one wave, in-order LDS: the reads below see every lane's writes)
+      float v0[16], v1[16];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int slot = 16 * s + 8 * (e >> 2) + 4 * half + (e & 3);
+          v0[8 * s + e] = vt[slot * VT_PITCH + vd0];
+          v1[8 * s + e] = vt[slot * VT_PITCH + vd1];
+        }
+      __builtin_amdgcn_wave_barrier();  // (the next job's writes stay behind these reads)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        ctk_split8(f32x4{v0[8 * s], v0[8 * s + 1], v0[8 * s + 2], v0[8 * s + 3]}, f32x4{v0[8 * s + 4], v0[8 * s + 5], v0[8 * s + 6], v0[8 * s + 7]},
+                   vh[0][s], vl[0][s]);
+        ctk_split8(f32x4{v1[8 * s], v1[8 * s + 1], v1[8 * s + 2], v1[8 * s + 3]}, f32x4{v1[8 * s + 4], v1[8 * s + 5], v1[8 * s + 6], v1[8 * s + 7]},
+                   vh[1][s], vl[1][s]);
+      }
     }
     const long next = job + stride;
     const bool more = next < njobs;  // wave-uniform

@@ -31,12 +31,36 @@ namespace {
 // for its SMEM result (~100 cycles per phase): periods are inflated uniformly, their RATIOS are what is read.
 constexpr int PP_TRACE_WGS = 4, PP_TRACE_STAMPS = 128, PP_TRACE_OFF = 155648;
 __device__ unsigned long long g_pp_trace[PP_TRACE_WGS * 8 * PP_TRACE_STAMPS];
+// (s_memtime, s_memrealtime) pair: the last four slots of a wave's trace hold it at kernel start and end -- s_memrealtime is the
+// constant 100 MHz counter, so the pair gives the rate s_memtime ticked at over the kernel's life
+__device__ __forceinline__ void pp_trace_clocks(unsigned char* dst, const int lane) {
+  unsigned long long a, b;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a), "=s"(b) : : "memory");
+  if (lane == 0) {
+    reinterpret_cast<unsigned long long*>(dst)[0] = a;
+    reinterpret_cast<unsigned long long*>(dst)[1] = b;
+  }
+}
+// Every launch (production kernels too): wave 0 of workgroup 0 leaves (s_memtime, s_memrealtime) at its start and end in g_pp_clock --
+// two scalar loads and two 16-byte stores per launch.  s_memrealtime ticks at 100 MHz, so the pair gives the shader clock the
+// launch actually ran at (ctk_debug_pp_clock; tools/gemm_lab clock): the GEMMs are power-capped, and by how much is a number.
+__device__ unsigned long long g_pp_clock[4];
+__device__ __forceinline__ void pp_clock_probe(const int which, const int tid) {
+  if (blockIdx.x == 0 && tid < 64) {
+    unsigned long long a, b;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a), "=s"(b) : : "memory");
+    if (tid == 0) {
+      g_pp_clock[2 * which] = a;
+      g_pp_clock[2 * which + 1] = b;
+    }
+  }
+}
 #define PP_STAMP()                                                                                                      \
   do {                                                                                                                  \
     if (DBG && tr_on) {                                                                                                 \
       unsigned long long t_;                                                                                            \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");                                     \
-      if (lane == 0 && tr_n < PP_TRACE_STAMPS) *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + tr_n * 8) = t_; \
+      if (lane == 0 && tr_n < PP_TRACE_STAMPS - 4) *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + tr_n * 8) = t_; \
       ++tr_n;                                                                                                           \
     }                                                                                                                   \
   } while (0)
@@ -45,10 +69,12 @@ __device__ unsigned long long g_pp_trace[PP_TRACE_WGS * 8 * PP_TRACE_STAMPS];
   int tr_n = 0;                                                                                                         \
   if (DBG && tr_on) {                                                                                                   \
     for (int i = lane; i < PP_TRACE_STAMPS; i += 64) *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + i * 8) = 0ull; \
+    pp_trace_clocks(lds + PP_TRACE_OFF + wave * 1024 + (PP_TRACE_STAMPS - 4) * 8, lane);                                  \
   }
 #define PP_TRACE_DUMP()                                                                                                 \
   do {                                                                                                                  \
     if (DBG && tr_on) {                                                                                                 \
+      pp_trace_clocks(lds + PP_TRACE_OFF + wave * 1024 + (PP_TRACE_STAMPS - 2) * 8, lane);                              \
       for (int i = lane; i < PP_TRACE_STAMPS; i += 64)                                                                  \
         g_pp_trace[((long)blockIdx.x * 8 + wave) * PP_TRACE_STAMPS + i] = *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + i * 8); \
     }                                                                                                                   \
@@ -233,7 +259,12 @@ __device__ __forceinline__ void pp_walk_epilogue(const CtkGemmP& g, const PPWalk
 // every wave has waited for its pieces of blocks <= g + 2 at the end of the load segment of phase g (vmcnt(8): the 4
 // younger blocks stay in flight), one s_barrier before any wave reads them.
 // LDS: A blocks at (J&1)*32K + a*16K, B blocks at 64K + (J&1)*32K + b*16K.
-template <int EPI, bool DBG, int TAG = 0>  // TAG: no code difference, only a distinct kernel NAME per Linear for rocprofv3 (tools/pmc_traffic.py)
+// DIM (round 5 experiment, ctk_gemm_pp_mode bit 7): the phase's LDS-DMA pieces are issued INSIDE its MFMA burst (behind the second
+// MFMA) instead of in the load segment in front of the barrier.  The wave timeline (profiles/r05_gemm_wave_timeline_before.txt)
+// shows a phase period of ~1150-1400 cycles against 2 x 384 of MFMA issue: the load segment (fragment reads + 2-3 DMA pieces at
+// 100-185 cycles each + their address arithmetic), not the matrix pipe, paces a phase.  A piece costs ~60 cycles among MFMAs.
+// The waits sit where they were; a phase's own pieces are now issued BEHIND its wait, so every count drops by that block.
+template <int EPI, bool DBG, int TAG = 0, int DIM = 0>  // TAG: no code difference, only a distinct kernel NAME per Linear for rocprofv3 (tools/pmc_traffic.py)
 __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
   const int dbg = DBG ? dbg_arg : 0;  // the experiment knobs exist only in the DBG instantiations
   constexpr int BM = 256, BN = 256;
@@ -257,6 +288,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
   pp_stage_bias<EPI>(g, lds + RING, tid);
   PP_TRACE_INIT();
+  pp_clock_probe(0, tid);
   if (dbg >> 8) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
     const int n = ((blockIdx.x >> 3) & 3) * (dbg >> 8);
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
@@ -329,18 +361,26 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   // (a workgroup that starts in the middle of a tile contributes K-tiles only: its accumulators start from 0 x residual)
   auto init_acc = [&](const float sc) { pp_init_acc<EPI, 4, 2>(acc, resid, lane, sc, scratch()); };
   // operands swapped on purpose (D'[n][m]: lane = output row, register quad = 4 consecutive columns); small terms first
-  auto mma = [&](const int a, const int b) {
+  auto mma_dma = [&](const int a, const int b, auto issue) {  // `issue` runs behind the second MFMA (DIM) or not at all
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+      for (int term = 0; term < 3; ++term) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[a * 2 + mi][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[b][j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0],
                                                                       acc[a * 2 + mi][b], 0, 0, 0);
+        if (DIM && j == 0 && term == 0) {
+          PP_SCHED_FENCE();
+          issue();
+          PP_SCHED_FENCE();
+        }
+      }
     __builtin_amdgcn_s_setprio(0);
   };
+  auto mma = [&](const int a, const int b) { mma_dma(a, b, [] {}); };
+  constexpr int WV = DIM ? 6 : 8;  // in flight behind a phase's wait: 3 blocks (DIM: its own block is not issued yet) or 4
 
   // ---- stream set-up: blocks 0..5 = K-tile 0 (all four) + K-tile 1 (A_0, B_0)
   PPCursor c1, c2;  // K-tiles J+1 and J+2 of the stream
@@ -368,38 +408,38 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
       // ---- phase 0 (a=0, b=0): read A_0, B_0; issue B_1 of K-tile J+1
       read_a(0);
       read_b(0);
-      dma_b(c1, 1, par ^ 1);
-      PP_WAIT_VM(8);
+      if (!DIM) dma_b(c1, 1, par ^ 1);
+      PP_WAIT_VM(WV);
       PP_BARRIER();
       PP_WAIT_LGKM0();
       PP_STAMP();
-      mma(0, 0);
+      mma_dma(0, 0, [&] { dma_b(c1, 1, par ^ 1); });
       PP_BARRIER();
       // ---- phase 1 (a=0, b=1): read B_1; issue A_1 of K-tile J+1
       read_b(1);
-      dma_a(c1, 1, par ^ 1);
-      PP_WAIT_VM(8);
+      if (!DIM) dma_a(c1, 1, par ^ 1);
+      PP_WAIT_VM(WV);
       PP_BARRIER();
       PP_WAIT_LGKM0();
       PP_STAMP();
-      mma(0, 1);
+      mma_dma(0, 1, [&] { dma_a(c1, 1, par ^ 1); });
       PP_BARRIER();
       // ---- phase 2 (a=1, b=1): read A_1; issue A_0 of K-tile J+2 (into the slot A_0 of this K-tile left in phase 0)
       read_a(1);
-      dma_a(c2, 0, par);
-      PP_WAIT_VM(8);
+      if (!DIM) dma_a(c2, 0, par);
+      PP_WAIT_VM(WV);
       PP_BARRIER();
       PP_WAIT_LGKM0();
       PP_STAMP();
-      mma(1, 1);
+      mma_dma(1, 1, [&] { dma_a(c2, 0, par); });
       PP_BARRIER();
       // ---- phase 3 (a=1, b=0): nothing to read (B_0 is still in registers); issue B_0 of K-tile J+2
-      dma_b(c2, 0, par);
-      PP_WAIT_VM(8);
+      if (!DIM) dma_b(c2, 0, par);
+      PP_WAIT_VM(WV);
       const bool last = kt + 1 == tile.ke;
       PP_BARRIER();
       PP_STAMP();
-      mma(1, 0);
+      mma_dma(1, 0, [&] { dma_b(c2, 0, par); });
       if (!last) PP_BARRIER();
       // advance the stream
       c1 = c2;
@@ -433,6 +473,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   if (grp == 0) PP_BARRIER();  // balance group 1's extra barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // duplicate tail blocks may still be landing
   PP_TRACE_DUMP();
+  pp_clock_probe(1, tid);
 }
 
 // ================================================================================================
@@ -444,7 +485,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
 // block i = 3 J + k is issued in phase i - 4 into the K-tile slot (J & 1) (56 KiB each), where block i - 6 was last read
 // >= 2 phases earlier; waits: end of phase 3J+2 -> I0, I1 of K-tile J+1 (vmcnt(5): I2(J+1) and I0(J+2) stay in flight),
 // end of phase 3J -> I2 of K-tile J (vmcnt(5)), end of phase 3J+1 -> nothing new.
-template <int EPI, bool DBG, int TAG = 0>
+template <int EPI, bool DBG, int TAG = 0, int DIM = 0>  // DIM: see gemm_pp256_kernel
 __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
   const int dbg = DBG ? dbg_arg : 0;
   constexpr int BM = 256, BN = 192;
@@ -468,6 +509,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   const float w_scale = reinterpret_cast<const float*>(g.Wp)[0], w_unscale = reinterpret_cast<const float*>(g.Wp)[1];
   pp_stage_bias<EPI>(g, lds + RING, tid);
   PP_TRACE_INIT();
+  pp_clock_probe(0, tid);
   if (dbg >> 8) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
     const int n = ((blockIdx.x >> 3) & 3) * (dbg >> 8);
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
@@ -593,15 +635,21 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
   };
-  auto mma = [&](const int n) {
+  auto mma_dma = [&](const int n, auto issue) {  // `issue` runs behind the second MFMA (DIM) or not at all
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+      for (int term = 0; term < 3; ++term) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][n], 0, 0, 0);
+        if (DIM && j == 0 && term == 0) {
+          PP_SCHED_FENCE();
+          issue();
+          PP_SCHED_FENCE();
+        }
+      }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -637,35 +685,36 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     read_a();
     read_b(0);
     if constexpr (RD0) res_read();
-    issue_i1(c1, par ^ 1);
-    PP_WAIT_VM(5);
+    if (!DIM) issue_i1(c1, par ^ 1);
+    PP_WAIT_VM(DIM ? 3 : 5);  // (DIM: behind I2 of this K-tile only I0 of the next one is in flight; I1 follows inside the MFMAs)
     PP_BARRIER();
     PP_WAIT_LGKM0();
     PP_STAMP();
-    mma(0);
+    mma_dma(0, [&] { issue_i1(c1, par ^ 1); });
     if constexpr (RD0) res_add(std::integral_constant<int, (RD0 ? I - 2 : 0)>{});
     PP_BARRIER();
     // ---- phase 1: read B_1; issue I2 of K-tile J+1
     read_b(1);
-    issue_i2(c1, par ^ 1);
+    if (!DIM) issue_i2(c1, par ^ 1);
     if constexpr (WR) res_write();
     if constexpr (LD) res_load(std::integral_constant<int, (LD ? I : 0)>{});
     PP_BARRIER();
     PP_WAIT_LGKM0();
     PP_STAMP();
-    mma(1);
+    mma_dma(1, [&] { issue_i2(c1, par ^ 1); });
     PP_BARRIER();
     // ---- phase 2: read B_2; issue I0 of K-tile J+2 (the A rows of this K-tile were read in phase 0); wait for I0, I1 of J+1
     read_b(2);
     if constexpr (RD2) res_read();
-    issue_i0(c2, par);
-    if constexpr (LD) PP_WAIT_VM(9);  // (the 4 residual pieces of phase 1 are younger than I2 of K-tile J+1)
-    else PP_WAIT_VM(5);
+    if (!DIM) issue_i0(c2, par);
+    // behind I0 / I1 of K-tile J+1: I2 of J+1 (2 pieces) and, where this K-tile carries them, the 4 residual pieces of phase 1 --
+    // in front of I2 when it is issued inside the MFMAs (DIM), behind it otherwise -- and (not DIM) I0 of K-tile J+2
+    PP_WAIT_VM((DIM ? 2 : 5) + (LD ? 4 : 0));
     const bool last = kt + 1 == tile.ke;
     PP_BARRIER();
     PP_WAIT_LGKM0();
     PP_STAMP();
-    mma(2);
+    mma_dma(2, [&] { issue_i0(c2, par); });
     if constexpr (RD2) res_add(std::integral_constant<int, (RD2 ? I - 1 : 0)>{});
     if (!last) PP_BARRIER();
     c1 = c2;
@@ -701,6 +750,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   if (grp == 0) PP_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PP_TRACE_DUMP();
+  pp_clock_probe(1, tid);
 }
 
 thread_local int t_pp_cu_limit = 0;
@@ -749,6 +799,13 @@ extern "C" void ctk_gemm_pp_mode(int mode) { g_pp_mode = mode; }
 
 // dev tool (tools/gemm_lab trace; not part of include/ctk.h): the wave timeline the last DBG launch with mode bit 6 recorded,
 // [PP_TRACE_WGS workgroups][8 waves][PP_TRACE_STAMPS] s_memtime values (0 = not written)
+// dev tool: {s_memtime, s_memrealtime (100 MHz)} at the start and at the end of workgroup 0 of the LAST persistent GEMM launch
+extern "C" int ctk_debug_pp_clock(unsigned long long* host_out4) {
+  if (!host_out4) return CTK_E_NULL;
+  const hipError_t e = hipMemcpyFromSymbol(host_out4, HIP_SYMBOL(g_pp_clock), 32);
+  return e == hipSuccess ? CTK_OK : (int)e;
+}
+
 extern "C" int ctk_debug_pp_trace(unsigned long long* host_out, int n) {
   if (!host_out || n <= 0 || n > PP_TRACE_WGS * 8 * PP_TRACE_STAMPS) return CTK_E_SHAPE;
   const hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_trace), (size_t)n * 8);
@@ -843,12 +900,16 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   CtkProfScope ps(pname, flops * frac, bytes * frac, s);
   // stream-K only on the stream whose entry point lent the scratch (one persistent GEMM at a time uses the slots)
   g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;
-  const bool dbgk = (g_pp_mode & ~(17 | 32)) != 0;  // (bit 6 = wave timeline: DBG kernels)
+  const bool dbgk = (g_pp_mode & ~(17 | 32 | 128)) != 0;  // (bit 6 = wave timeline: DBG kernels)
+  const bool dim = (g_pp_mode & 128) != 0;  // DMA pieces inside the MFMA bursts
 #define PP_CASE(E)                                                                                             \
   case E:                                                                                                      \
     if (t256 && dbgk) hipLaunchKernelGGL((gemm_pp256_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);   \
+    else if (t256 && dim) hipLaunchKernelGGL((gemm_pp256_kernel<E, false, 0, 1>), grid, blk, 0, s, g, (int)tiles, 0); \
     else if (t256) hipLaunchKernelGGL((gemm_pp256_kernel<E, false>), grid, blk, 0, s, g, (int)tiles, 0);       \
     else if (dbgk) hipLaunchKernelGGL((gemm_pp192_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);      \
+    else if (dim && g.K > 768) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 1, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
+    else if (dim) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 0, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
     else if (g.K > 768) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
     else hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 0>), grid, blk, 0, s, g, (int)tiles, 0);              \
     break

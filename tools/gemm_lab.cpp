@@ -35,6 +35,7 @@
   } while (0)
 
 extern "C" int ctk_debug_pp_trace(unsigned long long* host_out, int n);  // gemm_pp.hip dev entry (not in ctk.h)
+extern "C" int ctk_debug_pp_clock(unsigned long long* host_out4);
 
 struct Shape {
   const char* name;
@@ -122,7 +123,7 @@ int main(int argc, char** argv) {
     shapes.push_back({"kv  ragged M  ", 102400 - 200, 384, 768, CTK_ACT_NONE, false, false, false, true, 1});
   }
 
-  if (argc > 1 && !strcmp(argv[1], "trace") && shapes.size() > 6) shapes.resize(6);
+  if (argc > 1 && (!strcmp(argv[1], "trace") || !strcmp(argv[1], "clock")) && shapes.size() > 8) shapes.resize(8);
   std::mt19937 rng(1234);
   std::normal_distribution<float> nd(0.f, 1.f);
   int failures = 0;
@@ -219,6 +220,23 @@ int main(int argc, char** argv) {
       return ms / reps;
     };
 
+    if (argc > 1 && !strcmp(argv[1], "clock")) {
+      // the shader clock the PRODUCTION kernel runs at, after `reps` back-to-back launches (workgroup 0's lifetime of the last one)
+      const int mode = argc > 2 ? atoi(argv[2]) : 33;
+      const double ms = time_mode(dC1, mode);
+      HIP_OK(hipStreamSynchronize(st));
+      unsigned long long c[4];
+      CTK_OKAY(ctk_debug_pp_clock(c));
+      const double ticks = (double)(c[2] - c[0]), real = (double)(c[3] - c[1]);
+      printf("%s M=%7ld K=%4d N=%4d B=%d | mode %d: %8.1f us per launch | workgroup 0 alive %.1f us = %.0f cycles -> %.3f GHz\n", sh.name, M, K, N, B, mode,
+             ms * 1e3, real / 100.0, ticks, real > 0 ? ticks / real * 0.1 : 0.0);
+      fflush(stdout);
+      HIP_OK(hipFree(dA)); HIP_OK(hipFree(dAsh)); HIP_OK(hipFree(dW)); HIP_OK(hipFree(dC0)); HIP_OK(hipFree(dC1)); HIP_OK(hipFree(dC2));
+      HIP_OK(hipFree(dWp));
+      if (db) HIP_OK(hipFree(db));
+      if (dbr) HIP_OK(hipFree(dbr));
+      continue;
+    }
     if (argc > 1 && !strcmp(argv[1], "trace")) {
       // wave timeline of the DBG kernel (mode bit 6): s_memtime at the start of every MFMA phase + around every epilogue
       time_mode(dC1, 1);  // warm caches and clocks on the production kernel
@@ -234,8 +252,9 @@ int main(int argc, char** argv) {
         for (int wv : {0, 3, 4, 7}) {
           const unsigned long long* t = &tr[((size_t)wg * 8 + wv) * ST];
           int n = 0;
-          while (n < ST && t[n]) ++n;
-          printf("  wg %d wave %d: %d stamps;", wg, wv, n);
+          while (n < ST - 4 && t[n]) ++n;
+          const double ticks = (double)(t[ST - 2] - t[ST - 4]), real = (double)(t[ST - 1] - t[ST - 3]);  // s_memtime / s_memrealtime (100 MHz)
+          printf("  wg %d wave %d: %d stamps; kernel life %.0f ticks = %.1f us -> s_memtime at %.3f GHz;", wg, wv, n, ticks, real / 100.0, real > 0 ? ticks / real * 0.1 : 0.0);
           for (int tile = 0; tile * per_tile + per_tile <= n; ++tile) {
             const unsigned long long* b = t + tile * per_tile;
             // phase-to-phase periods by phase index, first K-tile apart
