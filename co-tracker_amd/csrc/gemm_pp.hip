@@ -510,7 +510,10 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   pp_stage_bias<EPI>(g, lds + RING, tid);
   PP_TRACE_INIT();
   pp_clock_probe(0, tid);
-  if (dbg >> 8) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
+  // power experiments (DBG only; tools/gemm_lab clock <mode>, profiles/r05_gemm_power_experiments.txt): bit 2 = issue no MFMA
+  // (everything else unchanged: what the operand feed alone costs), stagger field 255 = no fragment reads
+  const bool no_mfma = DBG && (dbg & 4) != 0, no_frag = DBG && (dbg >> 8) == 255;
+  if ((dbg >> 8) && !no_frag) {  // experiment: de-phase the workgroups (class = (blockIdx / 8) % 4 sleeps class * (dbg >> 8) * 8128 cycles)
     const int n = ((blockIdx.x >> 3) & 3) * (dbg >> 8);
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }
@@ -563,7 +566,9 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   };
   f16x8 fa[2][2][2];  // [mi][j][plane]
   f16x8 fb[2][2];     // [j][plane] of the current column block
+  bool kt_seen = false;  // (no_frag experiment: the first K-tile's fragments are read, later ones are not)
   auto read_a = [&]() {
+    if (no_frag && kt_seen) return;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
         for (int p = 0; p < 2; ++p) fa[mi][j][p] = *reinterpret_cast<const f16x8*>(lds + a_rd[j][p] + mi * 4096);
   };
   auto read_b = [&](const int n) {
+    if (no_frag && kt_seen) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -636,6 +642,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
   };
   auto mma_dma = [&](const int n, auto issue) {  // `issue` runs behind the second MFMA (DIM) or not at all
+    if (no_mfma) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -722,6 +729,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     par ^= 1;
     set_rd(par);
     ++kt;
+    kt_seen = true;
   };
   for (int q = 0;; ++q) {
     kt = tile.kb;
