@@ -759,24 +759,54 @@ __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long 
   const int vd0 = r32, vd1 = min(32 + r32, HD - 1);
   const int rb = r32 >> 4, ri = r32 & 15;  // batch of the pair / frame slot of my q and k row
 
+  // Round 5, second step: ROW-CONTIGUOUS loads.  A head's slice of a token row is 192 contiguous bytes = 12 sixteen-byte chunks;
+  // load i of lane l fetches chunk (64 i + l) % 12 of token slot (64 i + l) / 12, so the 64 lanes of an instruction walk along
+  // 5.3 rows instead of touching 32 rows x 16 bytes each: ~11 cache lines per instruction instead of 32 (every line of a slice
+  // was requested by up to three instructions).  The chunks go through the wave's LDS image ([32 slots][52 floats], one matrix at
+  // a time) and come back in the MFMA operand order; q, k and v all take this path.  Same values, same bits.
+  // (token slot, chunk) of my load i -- recomputed where needed: six more live registers spill
+  // (hipcc hoists the 6 LDS offsets and the 12 lane-dependent address parts out of the job loop and spills them -- a scratch
+  // reload inside the loop waits for the prefetched loads of the next job as well; `ln` is the lane id laundered through an
+  // empty asm inside the loop, so the arithmetic stays where it is used: ~12 VALU per load)
+  auto slot_of = [&](const int i, const int ln) { return ((64 * i + ln) * 43691) >> 19; };  // idx / 12, exact for idx < 384
+  auto chunk_of = [&](const int i, const int ln) { return (64 * i + ln) - 12 * slot_of(i, ln); };
   auto load = [&](long jb, TimeRaw& r) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     const int head = (int)(jb % CTK_HEADS);
     const int b0 = (int)(jb / CTK_HEADS) * 2;
-    const int bc = min(b0 + rb, p.nbatch - 1), ic = min(ri, p.n1 - 1);
-    const float* qp = p.q + ((long)bc * p.q_bs + (long)ic * p.q_is) * p.q_ld + head * HD + half * 8;
-    // (n1 == n2 here: my query row, my key row and my value row are the same token slot r32 = 16 * batch + frame)
-    const long krow = ((long)bc * p.kv_bs + (long)min(ri, p.n2 - 1) * p.kv_is) * p.kv_ld + head * HD + half * 8;
-    const float* kp = p.k + krow;
-    const float* vp = p.v + krow;
+    const float* qb = p.q + head * HD;
+    const float* kb = p.k + head * HD;
+    const float* vb = p.v + head * HD;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = slot_of(i, ln), c = chunk_of(i, ln);
+      const int bc = min(b0 + (row >> 4), p.nbatch - 1), fr = row & 15;
+      const long qo = ((long)bc * p.q_bs + (long)min(fr, p.n1 - 1) * p.q_is) * p.q_ld + c * 4;
+      const long ko = ((long)bc * p.kv_bs + (long)min(fr, p.n2 - 1) * p.kv_is) * p.kv_ld + c * 4;
+      r.q[i] = *reinterpret_cast<const f32x4*>(qb + qo);
+      r.k[i] = *reinterpret_cast<const f32x4*>(kb + ko);
+      r.v[i] = *reinterpret_cast<const f32x4*>(vb + ko);
+      __builtin_amdgcn_sched_barrier(0);  // (one load's address arithmetic at a time: all 18 at once spill)
+    }
+  };
+  // raw chunks of one matrix -> the wave's LDS image (token slot major, 52 floats per slot)
+  auto stage = [&](const f32x4 (&m)[6]) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(vt + slot_of(i, ln) * VT_PITCH + chunk_of(i, ln) * 4) = m[i];
+    __builtin_amdgcn_wave_barrier();  // (one wave, in-order LDS: the reads that follow see every lane's writes)
+  };
+  // image -> q / k operand rows: lane (slot r32, half) takes columns half*8 + 16 j + 0..7
+  auto frag_rows = [&](f32x4 (&f)[6]) {
+    const float* rr = vt + r32 * VT_PITCH + half * 8;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      r.q[2 * j] = *reinterpret_cast<const f32x4*>(qp + 16 * j);
-      r.q[2 * j + 1] = *reinterpret_cast<const f32x4*>(qp + 16 * j + 4);
-      r.k[2 * j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
-      r.k[2 * j + 1] = *reinterpret_cast<const f32x4*>(kp + 16 * j + 4);
-      r.v[2 * j] = *reinterpret_cast<const f32x4*>(vp + 16 * j);
-      r.v[2 * j + 1] = *reinterpret_cast<const f32x4*>(vp + 16 * j + 4);
+      f[2 * j] = *reinterpret_cast<const f32x4*>(rr + 16 * j);
+      f[2 * j + 1] = *reinterpret_cast<const f32x4*>(rr + 16 * j + 4);
     }
+    __builtin_amdgcn_wave_barrier();  // (the next matrix' writes stay behind these reads)
   };
 
   TimeRaw raw;
@@ -786,19 +816,19 @@ __global__ __launch_bounds__(256, 2) void attention_time16_kernel(AttnP p, long 
     const int b0 = (int)(job / CTK_HEADS) * 2;
     // raw f32 -> split-half fragments (the raw registers are dead afterwards and take the next job's loads)
     f16x8 qh[3], ql[3], kh[3], kl[3], vh[2][2], vl[2][2];
+    {
+      f32x4 f[6];
+      stage(raw.q);
+      frag_rows(f);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      ctk_split8(raw.q[2 * j] * p.scale2, raw.q[2 * j + 1] * p.scale2, qh[j], ql[j]);
-      ctk_split8(raw.k[2 * j], raw.k[2 * j + 1], kh[j], kl[j]);
+      for (int j = 0; j < 3; ++j) ctk_split8(f[2 * j] * p.scale2, f[2 * j + 1] * p.scale2, qh[j], ql[j]);
+      stage(raw.k);
+      frag_rows(f);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ctk_split8(f[2 * j], f[2 * j + 1], kh[j], kl[j]);
     }
-    {  // V rows -> LDS image -> V^T fragments: element (k-step s, e) of lane (dim, half) = V[slot 16 s + 8 (e >> 2) + 4 half + (e & 3)][dim]
-      float* wrow = vt + r32 * VT_PITCH + half * 8;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        *reinterpret_cast<f32x4*>(wrow + 16 * j) = raw.v[2 * j];
-        *reinterpret_cast<f32x4*>(wrow + 16 * j + 4) = raw.v[2 * j + 1];
-      }
-      __builtin_amdgcn_wave_barrier();  // (one wave, in-order LDS: the reads below see every lane's writes)
+    {  // V image -> V^T fragments: element (k-step s, e) of lane (dim, half) = V[slot 16 s + 8 (e >> 2) + 4 half + (e & 3)][dim]
+      stage(raw.v);
       float v0[16], v1[16];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
