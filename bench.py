@@ -191,6 +191,58 @@ def cpu_baseline(workload):
     return res
 
 
+def gemm_clock_probe(dev):
+    """The shader clock the persistent Linear kernels actually run at (round 5).  Workgroup 0 / wave 0 of every persistent GEMM
+    launch stamps (s_memtime, s_memrealtime) at its start and end (gemm_pp.hip: g_pp_clock; s_memrealtime is the constant 100 MHz
+    counter): cycles / time of the LAST of 8 back-to-back launches of a C3-window Linear = the clock under the power cap, and
+    mfma_issue_cycles / cycles = how much of the workgroup's life its SIMDs spent issuing MFMAs (12 per phase x 32 cycles, two
+    wave groups per SIMD).  The clock, not stalls, is what separates these kernels from the nominal roofline: they are power-capped
+    -- and in cycles they are bounded by the LDS-DMA operand feed (profiles/r05_gemm_power_experiments.txt)."""
+    import ctypes as C
+    from cotracker_amd import _lib as L
+    from cotracker_amd import ops
+    lib = L.load()
+    fn = lib.ctk_debug_pp_clock
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(C.c_ulonglong)]
+    out = {}
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for name, M, K, N, act, res, split in (("mlp.fc1", 103424, 384, 1536, 2, False, True), ("mlp.fc2", 103424, 1536, 384, 0, True, False),
+                                           ("to_q", 103424, 384, 384, 0, False, False), ("to_kv", 102400, 384, 768, 0, False, False)):
+        a = ops.split_rows(torch.randn(4096, K, generator=g).to(dev).repeat(M // 4096 + 1, 1)[:M].contiguous())
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        wp = ops.pack_weight(w)
+        b = torch.randn(N, generator=g).to(dev)
+        r = torch.randn(M, N, device=dev) if res else None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(9):
+            if i == 1:
+                e0.record()
+            if res:
+                ops.gemm(a, w, bias=b, act=act, resid=r, out=r, packed=wp)
+            else:
+                ops.gemm(a, w, bias=b, act=act, packed=wp, out_split=split)
+        e1.record()
+        e1.synchronize()
+        c = (C.c_ulonglong * 4)()
+        L.check(fn(c), "ctk_debug_pp_clock")
+        cycles, real = c[2] - c[0], c[3] - c[1]
+        t256 = N % 256 == 0
+        tiles = -(-M // 256) * (N // (256 if t256 else 192))
+        if not t256 or True:
+            rem = tiles % 256
+            if 0 < rem <= 64 and tiles > 256:
+                tiles -= rem  # the tail split leaves whole rounds to the persistent kernel
+        per_wg = -(-tiles // 256)
+        mfma_cycles = per_wg * (K // 32) * (4 if t256 else 3) * 2 * 12 * 32
+        out[name] = {"us_per_launch": round(e0.elapsed_time(e1) * 1e3 / 8, 1), "wg0_cycles": int(cycles), "wg0_us": round(real / 100.0, 1),
+                     "clock_ghz": round(cycles / real * 0.1, 3) if real else None,
+                     "mfma_issue_share_of_cycles": round(mfma_cycles / cycles, 3) if cycles else None}
+        del a, w, wp, b, r
+    torch.cuda.empty_cache()
+    return out
+
+
 def _traffic_fields(out, tr):
     if tr:
         out["traffic"] = tr.get("hbm_bytes_per_launch")
@@ -744,6 +796,11 @@ def main():
         except Exception as e:  # a reported calibration, never a reason to lose the bench line
             result["sustained_mfma"] = {"error": f"{type(e).__name__}: {e}"}
         result.update(rooflines(rows, traffic, sustained))
+        if args.workload == "c3_sliding" and args.precision == "f16x3":
+            try:
+                result["gemm_clock"] = gemm_clock_probe(dev)
+            except Exception as e:  # a reported diagnosis, never a reason to lose the bench line
+                result["gemm_clock"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and args.workload == "c3_sliding" and args.precision == "f16x3" and not args.no_extra_lines:
         # driver-timed versions of the numbers that used to exist only as builder-run files in profiles/ (<15 s together)
         extra = {}
