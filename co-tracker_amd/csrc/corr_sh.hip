@@ -33,6 +33,7 @@
 #include "ctk_profile.h"
 #include "gemm_params.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -685,6 +686,290 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh2_kernel(CorrShP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Version 3 (round 5): the footprint never touches LDS and the frame loop has ONE barrier per frame.
+//   * MFMA shape 16x16x32: wave w owns footprint rows 16 w .. 16 w + 15 (one pixel per lane & 15) against all 49 (64) tap
+//     columns, so a footprint row is needed by exactly one wave and its A fragments come STRAIGHT from the SH pyramid:
+//     lane (pixel i = lane & 15, k group g = lane >> 4) reads 16 bytes of plane pl of K-tile kt at
+//     pixel * 512 + kt * 128 + pl * 64 + g * 16 -- 8 loads per lane and frame (what version 1 issued to fill its LDS copy),
+//     no commit, no fragment ds_reads, no 44 KiB footprint buffer.  The support (B) fragments of all four 16-column tiles stay
+//     in 128 VGPRs over the chunk's frames; both operands use the same (g, element) -> k assignment, which is all a
+//     contraction needs.
+//   * C and the staging row are double buffered (2 x 21 KiB + 2 x 9.5 KiB), so between two barriers a wave carries three
+//     independent pieces of work of three different frames: store(t-2): staging[t & 1] -> split -> SH volume row;
+//     blend(t-1): C[(t-1) & 1] -> staging[(t-1) & 1]; MFMA(t) -> C[t & 1]; then the loads of frame t+1 (a whole iteration
+//     ahead of their use).  Version 1 needed two barriers per frame (C and staging single buffered) and parked its waves at
+//     them for 37 % of their lifetime (profiles/r04_pmc_corr.txt).
+//   * a footprint of more than 64 pixels (9 wide or tall: integer coordinates) has up to two more row tiles: waves 0 and 1
+//     load them, exposed, behind their own tile (rare).
+// Same values as version 1 up to f32 summation order (four accumulators per wave instead of even / odd K-tile pairs).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+constexpr int LDS3_BYTES = 2 * C_BYTES + 2 * STG_BYTES1 + TAB_BYTES;  // 65920
+static_assert(SUP_BYTES + 15 * 128 <= 2 * C_BYTES, "the support image (prologue only) aliases the C tables");
+static_assert(2 * LDS3_BYTES <= 160 * 1024, "two workgroups per CU");
+
+// DBG (dev-only bisection, CTK_CORR_DBG): 1 = no volume stores, 2 = every lane reads pixel 0 (no footprint traffic), 16 = no MFMAs,
+// 32 = no blend, 64 = no store phase at all (no staging reads, no splits)
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS3_BYTES];
+  float* Cb = reinterpret_cast<float*>(lds);                                  // [2][FROWS][CPITCH]
+  float* stgb = reinterpret_cast<float*>(lds + 2 * C_BYTES);                  // [2][CTK_CORR_LD]
+  unsigned char* sup = lds;                                                   // prologue only (aliases the C tables)
+  FrameTab* tabs = reinterpret_cast<FrameTab*>(lds + 2 * C_BYTES + 2 * STG_BYTES1);
+  float* cxy = reinterpret_cast<float*>(lds + 2 * C_BYTES + 2 * STG_BYTES1 + TC * 256);  // [TC][2]
+
+  unsigned bid = ctk_xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = bid % p.tchunks;
+  bid /= p.tchunks;
+  const int lvl = bid % CTK_LEVELS;
+  const int nl = bid / CTK_LEVELS;  // local point index
+  const int n = p.n0 + nl;
+  const int t0 = tc * TC;
+  const int nt = min(TC, p.S - t0);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  constexpr long ROW_H = 2 * CTK_CORR_LD;  // halves per SH volume row
+  _Float16* out_base = p.out + (long)lvl * p.out_level_stride + ((long)nl * p.S + t0) * ROW_H;
+
+  const bool live = p.mask ? (p.mask[n] != 0) : true;
+  if (!live) {  // support features of not-yet-queried tracks are zeroed (cotracker3_online.py:493-496)
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long i = tid; i < (long)nt * ROW_H / 8; i += 256) reinterpret_cast<f16x8*>(out_base)[i] = z;
+    return;
+  }
+
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float sx = p.sx[lvl], sy = p.sy[lvl];
+  const float inv = 1.0f / (float)(1 << lvl);  // coords / 2**i : exact
+  const _Float16* fm = p.fm[lvl];
+  if (DBG & 256) {  // dev: does any result depend on what the previous workgroup left in LDS?
+    for (int i = tid; i < LDS3_BYTES / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = (DBG & 1024) ? 0x7fc07fc0u : 0u;
+    __syncthreads();
+  }
+
+  // ---- prologue (as version 1): coordinates -> LDS; support patch -> split, scaled, swizzled image; tap tables ----
+  if (tid < 2 * nt) cxy[tid] = p.coords[((long)(t0 + (tid >> 1)) * p.N + n) * 2 + (tid & 1)];
+  {
+    const float* sp = p.support[lvl] + (long)n * CTK_TAPS * CTK_C;
+    f32x4 v[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int i = min(tid + 256 * j, CTK_TAPS * 32 - 1);
+      v[j] = *reinterpret_cast<const f32x4*>(sp + i * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+      if (i < CTK_TAPS * 32) {
+        f16x4 hi, lo;
+        ctk_split4(v[j] * FSCALE, hi, lo);
+        const int kt = c4 >> 3, k8 = (c4 & 7) >> 1, sub = c4 & 1;
+        const int fs = (row >> 1) & 7;
+        unsigned char* base = sup + kt * SUP_KT + row * 128 + sub * 8;
+        *reinterpret_cast<f16x4*>(base + ((k8 ^ fs) << 4)) = hi;
+        *reinterpret_cast<f16x4*>(base + (((4 + k8) ^ fs) << 4)) = lo;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 14 * nt) {
+    const int tl = tid / 14, j = tid - tl * 14, k = j % 7;
+    FrameTab* tab = tabs + tl;
+    if (j < 7) {
+      const float cx = __fmul_rn(cxy[2 * tl], inv);
+      const CtkTap a0 = ctk_tap(__fadd_rn(cx, -3.0f), W, sx);
+      const CtkTap t = ctk_tap(__fadd_rn(cx, (float)(k - 3)), W, sx);
+      tab->fx0[k] = t.i0 - a0.i0; tab->fx1[k] = t.i1 - a0.i0; tab->wx0[k] = t.w0; tab->wx1[k] = t.w1;
+      if (k == 6) { tab->xb = a0.i0; tab->fw = t.i1 - a0.i0 + 1; }
+    } else {
+      const float cy = __fmul_rn(cxy[2 * tl + 1], inv);
+      const CtkTap a0 = ctk_tap(__fadd_rn(cy, -3.0f), H, sy);
+      const CtkTap t = ctk_tap(__fadd_rn(cy, (float)(k - 3)), H, sy);
+      tab->fy0[k] = t.i0 - a0.i0; tab->fy1[k] = t.i1 - a0.i0; tab->wy0[k] = t.w0; tab->wy1[k] = t.w1;
+      if (k == 6) { tab->yb = a0.i0; tab->fh = t.i1 - a0.i0 + 1; }
+    }
+  }
+
+  // B fragments: tap column ct * 16 + i16, K-tile kt, k group g4 (chunk pl * 4 + g4 of the row's 128-byte line).  Rows 49..63
+  // of the last column tile read what follows the 49 rows of a K-tile: columns nobody stores.
+  f16x8 bh[NKT][4], bl[NKT][4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int row = ct * 16 + i16, fs = (row >> 1) & 7;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      bh[kt][ct] = *reinterpret_cast<const f16x8*>(sup + kt * SUP_KT + row * 128 + ((g4 ^ fs) << 4));
+      bl[kt][ct] = *reinterpret_cast<const f16x8*>(sup + kt * SUP_KT + row * 128 + (((4 + g4) ^ fs) << 4));
+    }
+  }
+  __syncthreads();  // tap tables visible; every wave has its B fragments: the image's LDS becomes the C tables
+  if (tid < CTK_CORR_LD - CTK_CORR_K) {  // K padding columns of both staging rows (never touched by the blend)
+    stgb[CTK_CORR_K + tid] = 0.0f;
+    stgb[CTK_CORR_LD + CTK_CORR_K + tid] = 0.0f;
+  }
+
+  // ---- A fragments of footprint row tile `tile` of frame tl: one pixel per lane & 15, 8 x 16 bytes -------------
+  f16x8 ah[NKT], al[NKT];
+  auto load_a = [&](int tl, int tile) {
+    const FrameTab* tab = tabs + tl;
+    const int fw = tab->fw, npx = fw * tab->fh;
+    const int r = min(tile * 16 + i16, npx - 1);  // rows past the footprint re-read its last pixel: never blended
+    int fy = (int)((float)r * __builtin_amdgcn_rcpf((float)fw));  // r / fw (r < 96, fw <= 9; 1-ulp reciprocal), fixed up below
+    fy -= (fy * fw > r);
+    fy += ((fy + 1) * fw <= r);
+    const int fx = r - fy * fw;
+    const _Float16* px = fm + (((long)(t0 + tl) * H + tab->yb + fy) * W + tab->xb + fx) * (2 * CTK_C) + g4 * 8;
+    if (DBG & 2) px = fm + g4 * 8;
+    // (Compiler-managed loads.  Inline-asm loads with counted waits that leave the three younger volume stores in flight were
+    // tried: not faster, and not safe -- nothing documents that a store cannot retire before an older load, so vmcnt(N) must
+    // not be used to skip stores.)
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      ah[kt] = *reinterpret_cast<const f16x8*>(px + kt * 64);
+      al[kt] = *reinterpret_cast<const f16x8*>(px + kt * 64 + 32);
+    }
+  };
+  // C[pixel][tap] of one row tile -> table Cw (f32, [88][60]; the 49 tap columns only).  Between two MFMAs on the same
+  // accumulator sit the three other column tiles.
+  auto mma_tile = [&](int tile, float* Cw) {
+    f32x4v acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (DBG & 16) {  // (keeps the loads alive)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct][0] += (float)(ah[kt][ct] + al[kt][ct]);
+        continue;
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kt], bh[kt][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kt], bl[kt][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kt], bh[kt][ct], acc[ct], 0, 0, 0);
+    }
+    // D: lane holds column i16 of the tile's rows 4 g4 + reg
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      if (ct * 16 + i16 < CTK_TAPS) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = tile * 16 + 4 * g4 + reg;
+          if (tile < 4 || row < FROWS) Cw[row * CPITCH + ct * 16 + i16] = acc[ct][reg] * UNSCALE;
+        }
+      }
+  };
+
+  // blend role of this thread (as version 1): tap p = tid / 5 dealt x-fastest, q chunk (tid % 5) * 12.  Threads 245..255 repeat
+  // tap 48's reads and write nothing.
+  const int bp = min(tid / 5, CTK_TAPS - 1), bq0 = (tid - (tid / 5) * 5) * 12;
+  const int bcnt = (tid < 245) ? (bq0 < 48 ? 12 : 1) : 0;
+  const int bwy = bp / 7, bhx = bp - bwy * 7;
+  const int bpo = bhx * 7 + bwy;  // the tap's column block in the volume row
+  // store role: the 608 sixteen-byte pieces of a volume row are dealt 152 (19 whole lines) to a wave: two full instructions and
+  // one of 24 lanes
+  const int sp0 = 152 * wave + lane;  // pieces sp0, sp0 + 64 and (lane < 24) sp0 + 128
+
+  // One iteration: MFMA(tl) -> C, the loads of frame tl+1 | store(tl-2) | blend(tl-1).  ST / BL / CUR are compile-time in the
+  // steady loop, so its body is (apart from the lane-masked writes) one straight line.
+  constexpr int PAR = (DBG & 4096) ? 1 : 0;  // dev: swap the roles of the two C / staging buffers
+  auto step = [&](int tl, bool ST, bool BL, bool CUR) {
+    if (DBG & 32) BL = false;
+    if (DBG & 64) ST = false;
+    // -- LDS reads of the two older frames first
+    f32x4 va[3], vb[3];
+    if (ST) {
+      const float* stg = stgb + ((tl + PAR) & 1) * CTK_CORR_LD;  // (tl - 2) & 1
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = min(sp0 + 64 * k, 152 * wave + 151), oct = (idx >> 3) * 4 + (idx & 3);
+        va[k] = reinterpret_cast<const f32x4*>(stg)[2 * oct];
+        vb[k] = reinterpret_cast<const f32x4*>(stg)[2 * oct + 1];
+      }
+    }
+    // The four corner weights as (w, w) register pairs the compiler cannot look into: the packed FMAs below then take plain
+    // operands.  Left alone, hipcc packs (w00, w10) / (w01, w11) into pairs and broadcasts with op_sel:[0,1,0] (low result lane
+    // reading the HIGH half of a source); on gfx950 a ds_write2_b32 issued right behind such a v_pk_fma_f32 stored a stale first
+    // data register in lanes 48..63 -- intermittently when the LDS queue was busy, every time when it was idle (round 5:
+    // profiles/r05_sampler_v3_pk_hazard.txt).  The op_sel_hi-only and plain forms never did.
+    f32x2v W00 = {0.0f, 0.0f}, W10 = W00, W01 = W00, W11 = W00;
+    const float *c00 = Cb, *c10 = Cb, *c01 = Cb, *c11 = Cb;
+    if (BL) {
+      const FrameTab* tb = tabs + (tl - 1);
+      const float* C = Cb + ((tl - 1 + PAR) & 1) * (C_BYTES / 4);
+      const int fw = tb->fw;
+      const int x0 = tb->fx0[bhx], x1 = tb->fx1[bhx], y0 = tb->fy0[bwy], y1 = tb->fy1[bwy];
+      const float wx0 = tb->wx0[bhx], wx1 = tb->wx1[bhx], wy0 = tb->wy0[bwy], wy1 = tb->wy1[bwy];
+      const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+      W00 = f32x2v{w00, w00}; W10 = f32x2v{w10, w10}; W01 = f32x2v{w01, w01}; W11 = f32x2v{w11, w11};
+      asm volatile("" : "+v"(W00), "+v"(W10), "+v"(W01), "+v"(W11));
+      c00 = C + (y0 * fw + x0) * CPITCH + bq0;
+      c10 = C + (y0 * fw + x1) * CPITCH + bq0;
+      c01 = C + (y1 * fw + x0) * CPITCH + bq0;
+      c11 = C + (y1 * fw + x1) * CPITCH + bq0;
+    }
+    // -- MFMAs of frame tl (its A fragments were requested a whole iteration ago), then the request for frame tl+1
+    if (CUR) {
+      float* Cw = Cb + ((tl + PAR) & 1) * (C_BYTES / 4);
+      mma_tile(wave, Cw);
+      const int npx = tabs[tl].fw * tabs[tl].fh;
+      if (npx > 64 && wave < 2 && 64 + 16 * wave < npx) {  // rare: rows 64..80
+        load_a(tl, 4 + wave);
+        mma_tile(4 + wave, Cw);
+      }
+      if (tl + 1 < nt) load_a(tl + 1, wave);
+    }
+    if (DBG & 512) __syncthreads();  // dev: a race between the MFMA / C-write part and the blend / store part?
+    // -- store(tl-2): staging row -> SH volume row, whole 128-byte lines per 8 lanes (see version 1)
+    if (ST && !(DBG & 1)) {
+      _Float16* orow = out_base + (long)(tl - 2) * ROW_H;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = sp0 + 64 * k, line = idx >> 3, c = idx & 7;
+        f16x8 hi, lo;
+        ctk_split8(va[k], vb[k], hi, lo);
+        const f16x8 v = (c < 4) ? hi : lo;
+        if (k < 2 || lane < 24) *reinterpret_cast<f16x8*>(orow + line * 64 + c * 8) = v;
+      }
+    }
+    // -- blend(tl-1): D[p][q] = sum over the 4 corners of w * C[corner pixel][q] (corner order and weight products of ATen
+    //    grid_sampler_3d: (x0,y0),(x1,y0),(x0,y1),(x1,y1))
+    if (BL) {
+      float* dst = stgb + ((tl - 1 + PAR) & 1) * CTK_CORR_LD + bpo * CTK_TAPS + bq0;
+      if (bcnt == 12) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const f32x4 a = reinterpret_cast<const f32x4*>(c00)[j], b = reinterpret_cast<const f32x4*>(c10)[j];
+          const f32x4 c = reinterpret_cast<const f32x4*>(c01)[j], d = reinterpret_cast<const f32x4*>(c11)[j];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {  // outputs 4 j + 2 h, + 1 as one register pair (and one ds_write2_b32)
+            const f32x2v a2 = {a[2 * h], a[2 * h + 1]}, b2 = {b[2 * h], b[2 * h + 1]};
+            const f32x2v c2 = {c[2 * h], c[2 * h + 1]}, d2 = {d[2 * h], d[2 * h + 1]};
+            const f32x2v o2 = __builtin_elementwise_fma(d2, W11, __builtin_elementwise_fma(c2, W01, __builtin_elementwise_fma(b2, W10, a2 * W00)));
+            dst[4 * j + 2 * h] = o2[0];
+            dst[4 * j + 2 * h + 1] = o2[1];
+          }
+        }
+      } else if (bcnt == 1) {  // q = 48
+        dst[0] = fmaf(c11[0], W11[0], fmaf(c01[0], W01[0], fmaf(c10[0], W10[0], c00[0] * W00[0])));
+      }
+    }
+    __syncthreads();
+  };
+
+  load_a(0, wave);
+  __syncthreads();  // staging pads written (iteration 0 itself only writes C[0])
+  int tl = 0;
+  for (; tl < 2; ++tl) step(tl, false, tl >= 1 && tl <= nt, tl < nt);
+  for (; tl < nt; ++tl) step(tl, true, true, true);
+  for (; tl <= nt + 1; ++tl) step(tl, true, tl <= nt, false);
+}
+
 // f32 rows -> SH with a power-of-two scale (pyramid conversion)
 __global__ void split_rows_scaled_kernel(const float* x, long n4, float scale, _Float16* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of a [*,128] matrix
@@ -751,7 +1036,16 @@ int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh
   const char* dbg = getenv("CTK_CORR_DBG");
   p.dbg = dbg ? atoi(dbg) : 0;
   const char* ver = getenv("CTK_CORR");
-  if (ver && atoi(ver) == 2) hipLaunchKernelGGL(corr_volume_sh2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  const int v = ver ? atoi(ver) : 1;
+  if (v == 2) hipLaunchKernelGGL(corr_volume_sh2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else if (v == 3) {
+    switch (p.dbg) {
+#define CTK_SH3(D) case D: hipLaunchKernelGGL(corr_volume_sh3_kernel<D>, dim3((unsigned)blocks), dim3(256), 0, s, p); break
+      CTK_SH3(1); CTK_SH3(2); CTK_SH3(3); CTK_SH3(16); CTK_SH3(32); CTK_SH3(48); CTK_SH3(64); CTK_SH3(112); CTK_SH3(256); CTK_SH3(512); CTK_SH3(1280); CTK_SH3(4096);
+#undef CTK_SH3
+      default: hipLaunchKernelGGL(corr_volume_sh3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
+  }
   else hipLaunchKernelGGL(corr_volume_sh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;

@@ -305,10 +305,11 @@ def test_corr_volume(golden, ops_model):
     assert maxdiff(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3]) == 0.0
 
 
-@pytest.mark.parametrize("version", ["1", "2"])
+@pytest.mark.parametrize("version", ["1", "2", "3"])
 def test_corr_volume_sh(golden, ops_model, version, monkeypatch):
     """Split-half sampler (footprint correlation on f16 MFMA x3, blend afterwards) vs the reference goldens.
-    version 2 = the opt-in wave-per-frame kernel with the blend on MFMA (CTK_CORR=2)."""
+    version 2 = the opt-in wave-per-frame kernel with the blend on MFMA (CTK_CORR=2); version 3 = footprint straight into the
+    16x16x32 MFMA's registers, one barrier per frame (CTK_CORR=3)."""
     from cotracker_amd import ops
     monkeypatch.setenv("CTK_CORR", version)
     g = golden("ops")
@@ -328,8 +329,8 @@ def test_corr_volume_sh(golden, ops_model, version, monkeypatch):
     assert torch.equal(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3])
 
 
-@pytest.mark.parametrize("version", ["1", "2"])
-@pytest.mark.parametrize("S", [5, 20])
+@pytest.mark.parametrize("version", ["1", "2", "3"])
+@pytest.mark.parametrize("S", [1, 2, 5, 20])
 def test_corr_volume_sh_stress_coordinates(S, version, monkeypatch):
     """Integer / half-integer / border / out-of-range coordinates (9-wide footprints, clamped taps), ragged frame
     chunks (S = 5: one short chunk; S = 20: 16 + 4) -- against the exact-f32 fused sampler (itself pinned to the goldens)."""
