@@ -746,11 +746,6 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
   const float sx = p.sx[lvl], sy = p.sy[lvl];
   const float inv = 1.0f / (float)(1 << lvl);  // coords / 2**i : exact
   const _Float16* fm = p.fm[lvl];
-  if (DBG & 256) {  // dev: does any result depend on what the previous workgroup left in LDS?
-    for (int i = tid; i < LDS3_BYTES / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = (DBG & 1024) ? 0x7fc07fc0u : 0u;
-    __syncthreads();
-  }
-
   // ---- prologue (as version 1): coordinates -> LDS; support patch -> split, scaled, swizzled image; tap tables ----
   if (tid < 2 * nt) cxy[tid] = p.coords[((long)(t0 + (tid >> 1)) * p.N + n) * 2 + (tid & 1)];
   {
@@ -877,14 +872,13 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
 
   // One iteration: MFMA(tl) -> C, the loads of frame tl+1 | store(tl-2) | blend(tl-1).  ST / BL / CUR are compile-time in the
   // steady loop, so its body is (apart from the lane-masked writes) one straight line.
-  constexpr int PAR = (DBG & 4096) ? 1 : 0;  // dev: swap the roles of the two C / staging buffers
   auto step = [&](int tl, bool ST, bool BL, bool CUR) {
     if (DBG & 32) BL = false;
     if (DBG & 64) ST = false;
     // -- LDS reads of the two older frames first
     f32x4 va[3], vb[3];
     if (ST) {
-      const float* stg = stgb + ((tl + PAR) & 1) * CTK_CORR_LD;  // (tl - 2) & 1
+      const float* stg = stgb + (tl & 1) * CTK_CORR_LD;  // (tl - 2) & 1
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int idx = min(sp0 + 64 * k, 152 * wave + 151), oct = (idx >> 3) * 4 + (idx & 3);
@@ -901,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
     const float *c00 = Cb, *c10 = Cb, *c01 = Cb, *c11 = Cb;
     if (BL) {
       const FrameTab* tb = tabs + (tl - 1);
-      const float* C = Cb + ((tl - 1 + PAR) & 1) * (C_BYTES / 4);
+      const float* C = Cb + ((tl - 1) & 1) * (C_BYTES / 4);
       const int fw = tb->fw;
       const int x0 = tb->fx0[bhx], x1 = tb->fx1[bhx], y0 = tb->fy0[bwy], y1 = tb->fy1[bwy];
       const float wx0 = tb->wx0[bhx], wx1 = tb->wx1[bhx], wy0 = tb->wy0[bwy], wy1 = tb->wy1[bwy];
@@ -915,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
     }
     // -- MFMAs of frame tl (its A fragments were requested a whole iteration ago), then the request for frame tl+1
     if (CUR) {
-      float* Cw = Cb + ((tl + PAR) & 1) * (C_BYTES / 4);
+      float* Cw = Cb + (tl & 1) * (C_BYTES / 4);
       mma_tile(wave, Cw);
       const int npx = tabs[tl].fw * tabs[tl].fh;
       if (npx > 64 && wave < 2 && 64 + 16 * wave < npx) {  // rare: rows 64..80
@@ -924,7 +918,6 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
       }
       if (tl + 1 < nt) load_a(tl + 1, wave);
     }
-    if (DBG & 512) __syncthreads();  // dev: a race between the MFMA / C-write part and the blend / store part?
     // -- store(tl-2): staging row -> SH volume row, whole 128-byte lines per 8 lanes (see version 1)
     if (ST && !(DBG & 1)) {
       _Float16* orow = out_base + (long)(tl - 2) * ROW_H;
@@ -940,7 +933,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
     // -- blend(tl-1): D[p][q] = sum over the 4 corners of w * C[corner pixel][q] (corner order and weight products of ATen
     //    grid_sampler_3d: (x0,y0),(x1,y0),(x0,y1),(x1,y1))
     if (BL) {
-      float* dst = stgb + ((tl - 1 + PAR) & 1) * CTK_CORR_LD + bpo * CTK_TAPS + bq0;
+      float* dst = stgb + ((tl - 1) & 1) * CTK_CORR_LD + bpo * CTK_TAPS + bq0;
       if (bcnt == 12) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1030,18 +1023,18 @@ int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh
   const double units = (double)ncount * a->S * CTK_LEVELS;
   CtkProfScope ps("corr_volume_sh", units * 2.0 * 49 * 49 * 128,
                   units * (64.0 * 128 * 4 + 49.0 * 128 * 4 / a->S + 2.0 + 2401.0 * 4), s);
-  // Dev knobs, read per call: CTK_CORR = 2 selects version 2 (wave per frame, register-fed footprint, MFMA blend);
-  // CTK_CORR_DBG = its bisection bits.  Measured on MI355X at the C3 window (tools/bench_corr.py): version 1
-  // 2.75 ms, version 2 3.0 ms per launch.
+  // Dev knobs, read per call: CTK_CORR selects the kernel version (default 3), CTK_CORR_DBG = bisection bits of versions 2 / 3.
+  // Measured on MI355X at the C3 window (tools/bench_corr.py, round 5): version 1 2.52-2.62 ms, version 2 2.98 ms,
+  // version 3 2.39-2.48 ms per launch.
   const char* dbg = getenv("CTK_CORR_DBG");
   p.dbg = dbg ? atoi(dbg) : 0;
   const char* ver = getenv("CTK_CORR");
-  const int v = ver ? atoi(ver) : 1;
+  const int v = ver ? atoi(ver) : 3;  // version 3 since round 5 (1 = the two-barrier LDS-footprint kernel, 2 = the wave-per-frame experiment)
   if (v == 2) hipLaunchKernelGGL(corr_volume_sh2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   else if (v == 3) {
     switch (p.dbg) {
 #define CTK_SH3(D) case D: hipLaunchKernelGGL(corr_volume_sh3_kernel<D>, dim3((unsigned)blocks), dim3(256), 0, s, p); break
-      CTK_SH3(1); CTK_SH3(2); CTK_SH3(3); CTK_SH3(16); CTK_SH3(32); CTK_SH3(48); CTK_SH3(64); CTK_SH3(112); CTK_SH3(256); CTK_SH3(512); CTK_SH3(1280); CTK_SH3(4096);
+      CTK_SH3(1); CTK_SH3(2); CTK_SH3(3); CTK_SH3(16); CTK_SH3(32); CTK_SH3(48); CTK_SH3(64); CTK_SH3(112);
 #undef CTK_SH3
       default: hipLaunchKernelGGL(corr_volume_sh3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     }

@@ -1,0 +1,35 @@
+"""What hipcc made of the sampler's blend (CPU: hipcc cross-compiles gfx950 without a GPU).
+
+Round 5 cornered an intermittent wrong result of sampler version 3 to one instruction pattern: a packed FP32 op whose LOW result
+lane reads the HIGH half of a source (`v_pk_fma_f32 ... op_sel:[0,1,0]`, which hipcc emits when it keeps two weights in one register
+pair) immediately in front of a `ds_write2_b32` of its result: lanes 48..63 stored a stale first data register (profiles/
+r05_sampler_v3_pk_hazard.txt).  The kernel now hands the packed FMAs plain (w, w) pairs; this test keeps a compiler upgrade from
+quietly bringing the pattern back in the default sampler."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "co-tracker_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
+def test_default_sampler_has_no_low_lane_op_sel_packed_ops(tmp_path):
+    out = tmp_path / "corr_sh.s"
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+           "--cuda-device-only", os.path.join(CSRC, "corr_sh.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = out.read_text().split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*corr_volume_sh3_kernelILi0EE.*:", l)]
+    assert len(starts) == 1, "the production instance of corr_volume_sh3_kernel"
+    end = next(i for i in range(starts[0], len(lines)) if "s_endpgm" in lines[i])
+    body = [l.strip() for l in lines[starts[0]:end]]
+    packed = [l for l in body if l.startswith("v_pk_")]
+    assert packed, "the blend is expected to use packed FP32 math (if it no longer does, this test can go)"
+    bad = [l for l in packed if re.search(r"op_sel:\[", l)]
+    assert not bad, f"packed ops whose low lane reads a high half: {bad[:4]}"
+    assert sum(l.startswith("v_mfma_f32_16x16x32_f16") for l in body) >= 48

@@ -54,6 +54,7 @@ NAME_MAP = [
     (r"gemm_f16x3_kernel<1, 1>", "gemm_f16x3_64x64"),
     (r"gemm_f32_kernel<2, 2>", "gemm_f32_128x128"),
     (r"gemm_f32_kernel<1, 1>", "gemm_f32_64x64"),
+    (r"corr_volume_sh3_kernel", "corr_volume_sh"),  # (round 5: the default sampler)
     (r"corr_volume_sh_kernel", "corr_volume_sh"),
     (r"corr_volume_kernel", "corr_volume"),
     (r"attention_merge_kernel", "attention_merge"),
