@@ -66,6 +66,7 @@ struct CorrShP {
   _Float16* out;        // [L][ncount*S][2*CTK_CORR_LD] halves
   long out_level_stride;
   int S, N, n0, ncount, tchunks;
+  int map;  // version 3: workgroup -> (point, level) dealing (dev knob CTK_CORR_MAP), see corr_volume_sh3_kernel
   int dbg;  // dev-only bisection bits (CTK_CORR_DBG): 1 = skip the volume stores, 2 = all lanes read pixel 0 (no footprint traffic), 4 = nontemporal volume stores, 8 = no cross-frame prefetch
 };
 
@@ -722,10 +723,42 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
   float* cxy = reinterpret_cast<float*>(lds + 2 * C_BYTES + 2 * STG_BYTES1 + TC * 256);  // [TC][2]
 
   unsigned bid = ctk_xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = bid % p.tchunks;
-  bid /= p.tchunks;
-  const int lvl = bid % CTK_LEVELS;
-  const int nl = bid / CTK_LEVELS;  // local point index
+  int tc, lvl, nl;
+  if (p.map == 3) {  // level-major (the default): consecutive ids = consecutive points of ONE level
+    nl = bid % p.ncount;
+    bid /= p.ncount;
+    lvl = bid % CTK_LEVELS;
+    tc = bid / CTK_LEVELS;
+  } else if (p.map == 4) {  // point-major inside blocks of 16 points: (16 points x level) x 4 levels, then the next 16 points
+    const unsigned blk = bid / (16 * CTK_LEVELS * p.tchunks), r = bid % (16 * CTK_LEVELS * p.tchunks);
+    if ((blk + 1) * 16 <= (unsigned)p.ncount) {
+      nl = blk * 16 + (r & 15);
+      lvl = (r >> 4) % CTK_LEVELS;
+      tc = (r >> 4) / CTK_LEVELS;
+    } else {  // the ragged tail: plain order
+      const unsigned t = bid - blk * 16 * CTK_LEVELS * p.tchunks;
+      tc = t % p.tchunks;
+      lvl = (t / p.tchunks) % CTK_LEVELS;
+      nl = blk * 16 + t / (p.tchunks * CTK_LEVELS);
+    }
+  } else if (p.map != 0 && (p.ncount & 1) == 0) {
+    // Neighbouring points (consecutive indices of a grid query) share most of their footprints; dealt as PAIRS at the same level to
+    // workgroups that run on one CU at the same time, the second one's loads can hit the first one's lines in the 32 KiB L1.
+    // map 1: the pair is (b, b + 32) inside a block of 64 consecutive workgroup ids; map 2: the pair is (b, b + 1).
+    unsigned u = bid;
+    if (p.map == 1 && (bid / 64 + 1) * 64 <= gridDim.x) u = (bid / 64) * 64 + (bid & 31) * 2 + ((bid >> 5) & 1);
+    const unsigned member = u & 1;
+    unsigned v = u >> 1;
+    tc = v % p.tchunks;
+    v /= p.tchunks;
+    lvl = v % CTK_LEVELS;
+    nl = (v / CTK_LEVELS) * 2 + member;
+  } else {
+    tc = bid % p.tchunks;
+    bid /= p.tchunks;
+    lvl = bid % CTK_LEVELS;
+    nl = bid / CTK_LEVELS;  // local point index
+  }
   const int n = p.n0 + nl;
   const int t0 = tc * TC;
   const int nt = min(TC, p.S - t0);
@@ -1028,6 +1061,12 @@ int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh
   // version 3 2.39-2.48 ms per launch.
   const char* dbg = getenv("CTK_CORR_DBG");
   p.dbg = dbg ? atoi(dbg) : 0;
+  // Workgroup -> (point, level) dealing of version 3.  Default 3 = level-major (consecutive workgroup ids, which the XCD remap
+  // keeps on one XCD, are consecutive points of ONE level: a grid query's neighbours share 60-90 % of their footprints, so the
+  // second one finds the lines in L1 / L2): 2.47 -> 2.25 ms per launch at the C3 window; 0 = point-major (levels innermost, the
+  // order of versions 1 / 2), 1 / 2 = point pairs, 4 = blocks of 16 points (profiles/r05_sampler_v3_bisect.txt).
+  const char* mp = getenv("CTK_CORR_MAP");
+  p.map = mp ? atoi(mp) : 3;
   const char* ver = getenv("CTK_CORR");
   const int v = ver ? atoi(ver) : 3;  // version 3 since round 5 (1 = the two-barrier LDS-footprint kernel, 2 = the wave-per-frame experiment)
   if (v == 2) hipLaunchKernelGGL(corr_volume_sh2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);

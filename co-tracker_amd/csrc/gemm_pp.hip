@@ -907,7 +907,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   snprintf(pname, sizeof(pname), "gemm_sh_pp%d_k%d_n%d", BN, g.K, g.N);
   CtkProfScope ps(pname, flops * frac, bytes * frac, s);
   // stream-K only on the stream whose entry point lent the scratch (one persistent GEMM at a time uses the slots)
-  g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;
+  g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && wgs == cus && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;  // (never under a CU limit: the slots are per CU of a full-width launch)
   const bool dbgk = (g_pp_mode & ~(17 | 32 | 128)) != 0;  // (bit 6 = wave timeline: DBG kernels)
   const bool dim = (g_pp_mode & 128) != 0;  // DMA pieces inside the MFMA bursts
 #define PP_CASE(E)                                                                                             \

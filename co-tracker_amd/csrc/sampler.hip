@@ -69,7 +69,7 @@ extern "C" int ctk_bilinear_sampler(const float* input, int32_t B, int32_t C, in
   if (!input || !coords || !out) return CTK_E_NULL;
   if (B <= 0 || C <= 0 || D < 0 || H <= 0 || W <= 0 || P <= 0 || B > 65535) return CTK_E_SHAPE;
   if (padding_mode != CTK_PAD_ZEROS && padding_mode != CTK_PAD_BORDER) return CTK_E_SHAPE;  // "reflection" is not implemented
-  if ((long)(D > 0 ? D : 1) * H * W > 2000000000L || (P + 255) / 256 > 2000000000L) return CTK_E_SHAPE;
+  if ((long)(D > 0 ? D : 1) * H * W > 2000000000L || (P + 255) / 256 > 16777215L) return CTK_E_SHAPE;  // gridDim.x * blockDim.x must stay below 2^32
   SampP p;
   p.in = input; p.coords = coords; p.out = out;
   p.B = B; p.C = C; p.D = D; p.H = H; p.W = W; p.P = P;

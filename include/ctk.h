@@ -431,7 +431,9 @@ typedef struct ctk_profile_row {
 } ctk_profile_row;
 int ctk_profile_enable(int on);
 /* Dev / A-B knob (process-global, not thread-safe): 1 (default) = the big split-half Linears (N % 256 == 0 or N % 192 == 0,
- * >= 128 tiles of 256 rows) run on the persistent ping-pong kernels of gemm_pp.hip, 0 = always gemm_f16x3.hip's kernels. */
+ * >= 128 tiles of 256 rows) run on the persistent ping-pong kernels of gemm_pp.hip, 0 = always gemm_f16x3.hip's kernels.
+ * Bit 4 (stream-K, off by default) adds ~64 MiB of scratch to every *_workspace_bytes answer: a workspace sized before the bit was
+ * set is too small afterwards (CTK_E_WORKSPACE) -- query again after changing it. */
 void ctk_gemm_pp_mode(int mode);
 int ctk_profile_read(ctk_profile_row* rows, int max_rows, int* nrows);
 /* Register-only MFMA loop (2 workgroups x 4 waves per CU) to calibrate the sustained peak of this
