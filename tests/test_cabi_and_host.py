@@ -181,3 +181,18 @@ def test_tail_aliases_cannot_prove_overlap_for_inference_tensors():
         w = torch.zeros(1, 16, 3, 8, 8)
         assert tail_aliases(w[:, 0:8], w[:, 4:12], 1, 4) is False
         assert tail_aliases(w[:, 0:8], w[:, 5:13], 1, 4) is False
+
+
+def test_bilinear_sampler_rejects_more_points_than_a_grid_can_cover():
+    """ctk_bilinear_sampler launches one thread per sample, 256 per workgroup: gridDim.x * blockDim.x must stay below 2^32, so
+    P > (2^24 - 1) * 256 is CTK_E_SHAPE before anything is launched (no GPU needed: the check precedes every HIP call)."""
+    import ctypes as C
+    from cotracker_amd import _lib as L
+    lib = L.load()
+    buf = (C.c_float * 4)()
+    ptr = C.cast(buf, C.c_void_p)
+    fn = lib.ctk_bilinear_sampler
+    too_many = ((1 << 24) - 1) * 256 + 1
+    rc = fn(ptr, 1, 1, 0, 2, 2, ptr, C.c_int64(too_many), 1, 1, ptr, None)
+    assert rc == -2  # CTK_E_SHAPE (include/ctk.h)
+    assert fn(ptr, 1, 1, 0, 2, 2, ptr, C.c_int64(0), 1, 1, ptr, None) == -2  # P <= 0

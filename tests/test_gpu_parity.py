@@ -681,18 +681,21 @@ def test_encoder_hip_vs_reference_fnet(golden, which):
     assert torch.equal(enc(video[2:7].float().contiguous()), nrm[2:7])
 
 
-def test_encoder_hip_at_model_resolution_vs_torch_cpu():
+@pytest.mark.parametrize("res", [(384, 512), (256, 256)])
+def test_encoder_hip_at_model_resolution_vs_torch_cpu(res):
     """BasicEncoder at the real 384 x 512 model resolution, where every 3 x 3 / stride-1 layer runs on the halo kernel (the toy
-    resolutions of the goldens are not tile-aligned and stay on conv_pp128_kernel): HIP vs the same module's torch forward on
-    the CPU in fp32 (the ops the reference calls), two frames; raw features <= 5e-6 of the feature scale, and each frame alone
-    gives the bits it has in the batch."""
+    resolutions of the goldens are not tile-aligned and stay on conv_pp128_kernel), and at 256 x 256, a MIX: layer1..layer3
+    (128, 64, 32 columns) qualify for the halo kernel, layer4 (16 columns) falls back to conv_pp128_kernel -- the two kernels are
+    not bit-identical, so a resolution decides which rounding a layer gets.  HIP vs the same module's torch forward on the CPU in
+    fp32 (the ops the reference calls), two frames; raw features <= 5e-6 of the feature scale, and each frame alone gives the
+    bits it has in the batch."""
     from cotracker_amd.encoder_hip import HipEncoder
     from cotracker_amd.model import CoTrackerThreeOnline
     from cotracker_amd.synthetic import synthetic_video
     from cotracker_amd.weights import fill_synthetic_
-    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=16).eval()
+    m = CoTrackerThreeOnline(stride=4, corr_radius=3, window_len=16, model_resolution=res).eval()
     fill_synthetic_(m, seed=3)
-    video = synthetic_video(2, 384, 512, seed=9)[0]
+    video = synthetic_video(2, res[0], res[1], seed=9)[0]
     with torch.no_grad():
         ref = m.fnet(2 * (video / 255.0) - 1.0).permute(0, 2, 3, 1).contiguous()
     m = m.to(dev())
