@@ -33,3 +33,52 @@ def test_default_sampler_has_no_low_lane_op_sel_packed_ops(tmp_path):
     bad = [l for l in packed if re.search(r"op_sel:\[", l)]
     assert not bad, f"packed ops whose low lane reads a high half: {bad[:4]}"
     assert sum(l.startswith("v_mfma_f32_16x16x32_f16") for l in body) >= 48
+
+
+FP_CONTRACT_OFF = {"corr", "corr_sh", "corrblock", "rowops", "v2ops", "encoder", "sampler"}  # as in csrc/Makefile
+
+
+def _compile_to_asm(name, out_dir):
+    out = os.path.join(out_dir, name + ".s")
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    if name in FP_CONTRACT_OFF:
+        cmd.append("-ffp-contract=off")
+    cmd += ["-S", "--cuda-device-only", os.path.join(CSRC, name + ".hip"), "-o", out]
+    subprocess.run(cmd, check=True, cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
+
+
+def _regs(text):
+    r = set()
+    for m in re.finditer(r"v\[(\d+):(\d+)\]", text):
+        r |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        r.add(int(m.group(1)))
+    return r
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
+def test_no_kernel_stores_the_result_of_a_low_lane_op_sel_packed_op_right_behind_it(tmp_path):
+    """The hazard of round 5 in its general form, over every kernel of the library: a packed FP32 op with a low-lane op_sel
+    (`op_sel:[...]` with a 1 in it) whose result register is the DATA of an LDS / global store within the next six
+    instructions.  None today (rowops.hip, encoder.hip and corr.hip contain such packed ops, but their results go through
+    further VALU instructions first)."""
+    from concurrent.futures import ThreadPoolExecutor
+    names = sorted(f[:-4] for f in os.listdir(CSRC) if f.endswith(".hip") and f not in ("api.hip", "profile.hip"))
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        outs = list(ex.map(lambda n: _compile_to_asm(n, str(tmp_path)), names))
+    risky = []
+    for path in outs:
+        lines = [l.strip() for l in open(path).read().split("\n") if l.startswith("\t") and not l.strip().startswith(";")]
+        for i, t in enumerate(lines):
+            if not (t.startswith("v_pk_") and re.search(r"op_sel:\[[01,]*1", t)):
+                continue
+            m = re.match(r"\S+\s+v\[(\d+):(\d+)\]", t)
+            if not m:
+                continue
+            dest = set(range(int(m.group(1)), int(m.group(2)) + 1))
+            for x in lines[i + 1:i + 7]:
+                if re.match(r"(ds_write|ds_store|global_store|buffer_store|flat_store)", x) and (_regs(x) & dest):
+                    risky.append((os.path.basename(path), t, x))
+                    break
+    assert not risky, risky[:5]
