@@ -1,10 +1,11 @@
 """What hipcc made of the sampler's blend (CPU: hipcc cross-compiles gfx950 without a GPU).
 
-Round 5 cornered an intermittent wrong result of sampler version 3 to one instruction pattern: a packed FP32 op whose LOW result
-lane reads the HIGH half of a source (`v_pk_fma_f32 ... op_sel:[0,1,0]`, which hipcc emits when it keeps two weights in one register
-pair) immediately in front of a `ds_write2_b32` of its result: lanes 48..63 stored a stale first data register (profiles/
-r05_sampler_v3_pk_hazard.txt).  The kernel now hands the packed FMAs plain (w, w) pairs; this test keeps a compiler upgrade from
-quietly bringing the pattern back in the default sampler."""
+Round 5 tied an intermittent wrong result of sampler version 3 to one compiler-chosen operand form: a packed FP32 op whose LOW
+result lane reads the HIGH half of a source (`v_pk_fma_f32 ... op_sel:[0,1,0]`, which hipcc emits when it keeps two weights in one
+register pair) right in front of a `ds_write2_b32` of its result: in every build containing the form, lanes 48..63 stored a wrong
+first data register; in every build without it, none (profiles/r05_sampler_v3_pk_hazard.txt -- an in-situ correlation: the sequence
+replayed in isolation does not fail).  The kernel now hands the packed FMAs plain (w, w) pairs; these tests keep a compiler upgrade
+from quietly bringing the form back."""
 import os
 import re
 import shutil
