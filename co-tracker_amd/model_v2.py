@@ -123,7 +123,11 @@ class PackedWeightsV2:
         head_w[: model.latent_dim + 2] = sd[u + "flow_head.weight"]
         head_b = torch.zeros(OUT_LD, device=device)
         head_b[: model.latent_dim + 2] = sd[u + "flow_head.bias"]
-        fw.head_w, fw.head_p, fw.head_b = hold(head_w), pack(head_w), hold(head_b)
+        # flow_head (384 -> 128 feature delta + 2 coordinates) always runs on the exact-f32 MFMA kernel (head_p = null): its output
+        # re-enters the track features six times per window, and with split-half products this ONE Linear took the visibility logit
+        # of the BASELINE-scale run from 5.1e-5 to 1.04e-4 against the reference (bar 1e-4; round-6 bisect, profiles/
+        # r06_v2_flow_head_bisect.txt: track_feat_updater in f32 changes nothing).  It is 0.3 % of the update's flops.
+        fw.head_w, fw.head_p, fw.head_b = hold(head_w), None, hold(head_b)
 
         def block(prefix, attn_name, cross):
             b = L.BlockWeights()
