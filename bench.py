@@ -197,11 +197,15 @@ def gemm_clock_probe(dev):
     counter): cycles / time of the LAST of 8 back-to-back launches of a C3-window Linear = the clock under the power cap, and
     mfma_issue_cycles / cycles = how much of the workgroup's life its SIMDs spent issuing MFMAs (12 per phase x 32 cycles, two
     wave groups per SIMD).  The clock, not stalls, is what separates these kernels from the nominal roofline: they are power-capped
-    -- and in cycles they are bounded by the LDS-DMA operand feed (profiles/r05_gemm_power_experiments.txt)."""
+    (profiles/r06_feed_lab.txt: the same loop runs at 2.4 GHz on zero operands and at 1.8 GHz on random ones).  DEV builds only."""
     import ctypes as C
     from cotracker_amd import _lib as L
     from cotracker_amd import ops
     lib = L.load()
+    if not hasattr(lib, "ctk_debug_pp_clock"):
+        # the release library carries no instruments (round 6): the clock readings need `make dev` + CTK_LIB_PATH=libctk_hip_dev.so
+        return {"unavailable": "release build of libctk_hip.so has no ctk_debug_pp_clock; round-6 readings of the same kind "
+                               "(zero vs random operands, clock per variant): profiles/r06_feed_lab.txt"}
     fn = lib.ctk_debug_pp_clock
     fn.restype = C.c_int
     fn.argtypes = [C.POINTER(C.c_ulonglong)]

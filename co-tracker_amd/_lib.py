@@ -20,8 +20,11 @@ HID = 384
 MLP = 1536
 VIRT = 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 PAD_ZEROS, PAD_BORDER = 0, 1  # ctk_bilinear_sampler padding_mode
+# ctk_set_option keys (include/ctk.h)
+(OPT_GEMM_PP, OPT_GEMM_TAIL_PCT, OPT_CORR_VERSION, OPT_CORR_MAP, OPT_ATTENTION_VALU, OPT_ATTENTION_TIME_PERSISTENT,
+ OPT_OVERLAP) = range(7)
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -172,8 +175,8 @@ SYMBOLS = {
     "ctk_attention": (C.c_int, [_P(AttnArgs), _fp]),
     "ctk_profile_enable": (C.c_int, [C.c_int]),
     "ctk_gemm_pp_mode": (None, [C.c_int]),
-    "ctk_gemm_scratch_bytes": (C.c_int, [_P(C.c_size_t)]),
-    "ctk_gemm_set_scratch": (C.c_int, [C.c_void_p, C.c_size_t, _fp]),
+    "ctk_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "ctk_get_option": (C.c_int, [C.c_int, _P(C.c_int)]),
     "ctk_profile_read": (C.c_int, [_P(ProfileRow), C.c_int, _P(C.c_int)]),
     "ctk_probe_mfma": (C.c_int, [C.c_int, C.c_int, _fp, _P(C.c_double), _fp]),
 }
@@ -204,6 +207,26 @@ def load():
         raise RuntimeError("libctk_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+class option:
+    """`with option(OPT_CORR_VERSION, 1): ...` -- set a back-end option (include/ctk.h: ctk_set_option) for a scope and restore the
+    previous value afterwards.  Process-wide (the table is one per loaded library): meant for tests and A/B tools."""
+
+    def __init__(self, key: int, value: int):
+        self.key, self.value, self.old = key, value, None
+
+    def __enter__(self):
+        lib = load()
+        old = C.c_int(0)
+        check(lib.ctk_get_option(self.key, C.byref(old)), "ctk_get_option")
+        self.old = old.value
+        check(lib.ctk_set_option(self.key, self.value), f"ctk_set_option({self.key}, {self.value})")
+        return self
+
+    def __exit__(self, *exc):
+        load().ctk_set_option(self.key, self.old)
+        return False
 
 
 def check(rc: int, what: str):

@@ -3,6 +3,7 @@
 #include "ctk_common.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
+#include "ctk_options.h"
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -83,23 +84,16 @@ int stream_follow(hipStream_t from, hipStream_t to) {
   return rc == hipSuccess ? CTK_OK : (int)rc;
 }
 
-// Knob CTK_OVERLAP (read per call): 0 = ignore aux_stream (everything on the caller's stream), bit 1 = software
-// pipeline sampler || corr_mlp, bit 2 = points<-virtual query projection beside the virtual-track chain, bit 4 (round 4) =
-// the time blocks' q projection beside their kv projection (tail filling between two persistent GEMMs), bit 8 (round 4) = the
-// points<-virtual query projection beside the SMALL launches of the virtual-track chain only, on a limited number of CUs.
-// DEFAULT 0: measured on MI355X at C3 (profiles/r02_overlap_and_time_attention_ab.txt) the sampler and the corr_mlp GEMM
-// do NOT complement each other -- run side by side each slows down by more than the other gains (sampler 2.70 -> 4 x
-// 1.21 ms, fc1 2.24 -> 4 x 0.77 ms per iteration; step 1528.5 -> 1547.3 ms) -- and the side query projection is worth
-// 0.15 % (1526.1 ms), inside run-to-run noise.  Results are bit-identical in every mode (tests), so the code stays
-// as an opt-in for other shapes.
-int side_cus() {  // CTK_SIDE_CUS (dev knob, read once): workgroups the side projection's persistent GEMM may occupy in overlap mode 8
-  static const int n = [] { const char* e = getenv("CTK_SIDE_CUS"); return e ? atoi(e) : 192; }();
-  return n;
-}
-int overlap_mode() {  // dev knob, read ONCE (getenv on the enqueue path races with setenv in multithreaded hosts)
-  static const int mode = [] { const char* e = getenv("CTK_OVERLAP"); return e ? atoi(e) : 0; }();
-  return mode;
-}
+// CTK_OPT_OVERLAP (ctk_set_option; initial value from CTK_OVERLAP when the library is loaded): 0 = ignore aux_stream (everything on
+// the caller's stream), bit 0 = software pipeline sampler || corr_mlp, bit 1 = points<-virtual query projection beside the
+// virtual-track chain.  DEFAULT 0: measured on MI355X at C3 (profiles/r02_overlap_and_time_attention_ab.txt) the sampler and the
+// corr_mlp GEMM do NOT complement each other -- run side by side each slows down by more than the other gains (sampler 2.70 -> 4 x
+// 1.21 ms, fc1 2.24 -> 4 x 0.77 ms per iteration; step 1528.5 -> 1547.3 ms) -- and the side query projection is worth 0.15 %
+// (1526.1 ms), inside run-to-run noise.  Results are bit-identical in every mode (tests), so the code stays as an opt-in for
+// other shapes.  Two more placements were measured in round 4 and removed in round 6 (both +-0: the time blocks' q projection
+// beside their kv projection, profiles/r04_overlap_qkv_ab.txt; the side projection on a limited number of CUs beside the small
+// launches of the virtual-track chain, profiles/r04_overlap8_trace.txt).
+int overlap_mode() { return ctk_opt(CTK_OPT_OVERLAP); }
 
 // Joins `aux` back into `main` when a fork is still open at scope exit (an error return between fork and join would
 // otherwise leave the auxiliary stream unjoined -- inside ctk_window_graph_create: stuck in a broken capture).
@@ -152,8 +146,6 @@ struct UfWs {
   float* att;     // [R,384]
   float* hid;     // [R,1536]
   float* partial; // attention split-K partials
-  void* sk;       // stream-K scratch of the persistent GEMMs (gemm_pp.hip): flags + one accumulator tile per CU
-  size_t sk_bytes;
   size_t bytes;
 };
 
@@ -181,8 +173,6 @@ UfWs carve_uf(int S, int N, void* base) {
   w.att = take(R * CTK_HID);
   w.hid = take(R * CTK_MLP);
   w.partial = take((size_t)v2p_splits(N) * S * CTK_HEADS * CTK_VIRT * (CTK_HEAD_DIM + 2));
-  w.sk_bytes = ctk_pp_scratch_bytes_if_enabled();  // 0 unless ctk_gemm_pp_mode bit 4 (stream-K) is set
-  w.sk = w.sk_bytes ? take((w.sk_bytes + 3) / 4) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -260,15 +250,8 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     {
       const ctk_block_weights& b = w->time_blocks[i];
       CTK_TRY(ctk_layernorm(tok, xn, R, nullptr, nullptr, 1e-6f, sp, s));
-      // to_q and to_kv read the same xn and write disjoint columns of qkv: with an auxiliary stream (CTK_OVERLAP bit 4, opt-in)
-      // the q projection is enqueued beside the kv projection, so that the persistent kv kernel's workgroups take the CUs
-      // the q kernel's last, 1/6-full round leaves idle (a persistent GEMM owns a CU's whole LDS: nothing else can overlap).
-      const bool par_q = fr.aux != nullptr && (overlap_mode() & 4) != 0;
-      JoinGuard qside{s, fr.aux};
-      if (par_q) CTK_TRY(qside.fork());
-      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, par_q ? fr.aux : s, nullptr, 0, 1, 0, 0, 0, sp, false));
+      CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(gemm(xn, CTK_HID, (int)R, WRef{b.wkv, b.wkv_p}, CTK_HID, 2 * CTK_HID, CTK_HID, qkv + CTK_HID, QL, b.bkv, CTK_ACT_NONE, nullptr, 0, s, nullptr, 0, 1, 0, 0, 0, sp, false));
-      if (par_q) CTK_TRY(qside.join());
       CTK_TRY(attn(qkv, QL, S, 1, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, S, 1, att, S, 1, N + CTK_VIRT, S, S, 1, nullptr, s, sp));
       CTK_TRY(gemm(att, CTK_HID, (int)R, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok, CTK_HID, b.bo, CTK_ACT_NONE, tok, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(mlp_block(ws, 0, R, b, s, sp));
@@ -278,24 +261,18 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
     // chain below (virtual<-points attention, two 1024-row MLPs, virtual self attention: ~16 launches that occupy a
     // fraction of the chip), into its own xn2 buffer and the (otherwise unused) q columns of the point rows of qkv.
     if (!fr.space_attn) continue;
-    // Two placements of that side work (both bit-identical to the single-stream order: same launches, same inputs):
-    //   bit 2: forked at the start of the space block -- measured useless (profiles/r02_overlap_and_time_attention_ab.txt): its
-    //          persistent to_q kernel and the main stream's persistent to_kv kernel each want every CU's whole LDS and serialise;
-    //   bit 8 (round 4): forked BEHIND the virtual<-points attention, i.e. beside the ~16 small launches of the virtual-track chain
-    //          only, and with the persistent GEMM limited to side_cus() workgroups (CtkPPCuLimit) so that the chain's kernels --
-    //          which cannot share a CU with a workgroup that owns all of its LDS -- find free CUs.
-    const bool late_q = fr.aux != nullptr && (overlap_mode() & 8) != 0;
-    const bool side_q = late_q || (fr.aux != nullptr && (overlap_mode() & 2) != 0);
+    // (bit-identical to the single-stream order: same launches, same inputs; measured useless at C3 -- the side stream's persistent
+    // to_q kernel and the main stream's persistent to_kv kernel each want every CU's whole LDS and serialise)
+    const bool side_q = fr.aux != nullptr && (overlap_mode() & 2) != 0;
     JoinGuard side{s, fr.aux};
     auto side_work = [&]() -> int {
       const ctk_block_weights& b = w->point2virtual[i];
       CTK_TRY(side.fork());
-      CtkPPCuLimit lim(late_q ? side_cus() : 0);
       CTK_TRY(ctk_layernorm(tok, ws.xn2, P, nullptr, nullptr, 1e-6f, sp, fr.aux));                                          // norm1(points)
       CTK_TRY(gemm(ws.xn2, CTK_HID, (int)P, WRef{b.wq, b.wq_p}, CTK_HID, CTK_HID, CTK_HID, qkv, QL, b.bq, CTK_ACT_NONE, nullptr, 0, fr.aux, nullptr, 0, 1, 0, 0, 0, sp, false));
       return CTK_OK;
     };
-    if (side_q && !late_q) CTK_TRY(side_work());
+    if (side_q) CTK_TRY(side_work());
     // ---- virtual <- points cross attention                          cotracker.py:510-512
     {
       const ctk_block_weights& b = w->virtual2point[i];
@@ -309,7 +286,6 @@ int run_transformer(int S, int N, const FormerRef& fr, const UfWs& ws, hipStream
       // batch = frame t; query i = virtual track (row P + i*S + t); key j = point (row j*S + t)
       CTK_TRY(attn(qkv + P * QL, QL, 1, S, qkv + CTK_HID, qkv + 2 * CTK_HID, QL, 1, S, att + P * CTK_HID, 1, S, S, CTK_VIRT, N,
                    v2p_splits(N), ws.partial, s, sp, fr.point_mask, nullptr));  // mask over KEYS (cotracker.py:566-569)
-      if (late_q) CTK_TRY(side_work());  // the auxiliary stream follows the attention; the small launches below run beside it
       CTK_TRY(gemm(att + P * CTK_HID, CTK_HID, (int)V, WRef{b.wo, b.wo_p}, CTK_HID, CTK_HID, CTK_HID, tok + P * CTK_HID, CTK_HID, b.bo, CTK_ACT_NONE,
                    tok + P * CTK_HID, CTK_HID, s, nullptr, 0, 1, 0, 0, 0, sp, false));
       CTK_TRY(mlp_block(ws, P, V, b, s, sp));
@@ -491,7 +467,6 @@ extern "C" int ctk_update_former(int32_t S, int32_t N, const float* x, const ctk
   const UfWs ws = carve_uf(S, N, workspace);
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  CtkPPScratchScope sk(ws.sk, ws.sk_bytes, s);
   CTK_TRY(input_projection(S, N, x, false, w, ws, s));
   CTK_TRY(run_transformer(S, N, former_of(w), ws, s));
   return ctk_launch_heads(ws.tokens, w->head_w, w->head_b, S, N, delta, nullptr, nullptr, nullptr, s);
@@ -519,7 +494,6 @@ extern "C" int ctk_update_former_ex(int32_t S, int32_t N, const void* x, int32_t
   const UfWs ws = carve_uf(S, N, workspace);
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  CtkPPScratchScope sk(ws.sk, ws.sk_bytes, s);
   // tokens = input_transform(x) (+ per-frame bias rows = W e_t + b when in_bias_t is given, else + in_b)
   CTK_TRY(gemm(static_cast<const float*>(x), w->in_ld, N * S, WRef{w->in_w, w->in_p}, w->in_ld, CTK_HID, w->in_ld, ws.tokens, CTK_HID,
                w->in_bias_t ? nullptr : w->in_b, CTK_ACT_NONE, nullptr, 0, s, w->in_bias_t, S, 1, 0, 0, w->in_dim, x_split != 0, false));
@@ -591,7 +565,6 @@ extern "C" int ctk_forward_window(const ctk_window_args* a, const ctk_model_weig
   const CorrWs cws = carve_corr(a, base + off);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool sp = split_mode(w);  // split mode: the transformer input x is kept in SH format
-  CtkPPScratchScope sk(uws.sk, uws.sk_bytes, s);  // every large Linear of the window runs on s, one at a time
   if (sp && a->iters > 0) CTK_TRY(prepare_pyramid_sh(a, cws, s));
   for (int it = 0; it < a->iters; ++it) {                       // cotracker3_online.py:187
     CTK_TRY(run_corr_embed(a, w, x, sp, cws, s));               // :190-210

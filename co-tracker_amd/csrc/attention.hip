@@ -13,6 +13,7 @@
 // of the [(N+64), S, 384] token tensor are both reached without the reference's
 // permute+contiguous copies (cotracker.py:494,504,520).
 #include "ctk_common.h"
+#include "ctk_options.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
 #include <cstdlib>
@@ -387,7 +388,10 @@ __global__ __launch_bounds__(256) void attention_kv64_kernel(AttnP p) {
 // softmax per query with the running max shared by the lane pair, then the four waves' (m, l, acc) states are
 // merged through LDS and written either as the final rows (one split) or as a partial for attention_merge_kernel.
 __global__ __launch_bounds__(256) void attention_q64_kernel(AttnP p) {
-  __shared__ float red[4][64][HD + 2];
+  // (16-byte aligned: the per-wave slices double as the V-transpose image and are written with f32x4 stores through `vt`)
+  __shared__ __attribute__((aligned(16))) float red[4][64][HD + 2];
+  static_assert(VT_BYTES <= (int)sizeof(float) * 64 * (HD + 2), "the V transpose image fits a wave's slice of red");
+  static_assert((VT_PITCH * 4) % 16 == 0 && (64 * (HD + 2) * 4) % 16 == 0, "16-byte rows / slices for ds_write_b128");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r32 = lane & 31, half = lane >> 5;
   const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
 
@@ -943,12 +947,8 @@ __global__ void attention_merge_kernel(AttnP p) {
   }
 }
 
-// Dev knob, read at every call (tests flip it): CTK_ATTN = 0 / unset: MFMA kernels for the 64-key, 64-query and
-// square shapes | 1: the VALU kernel everywhere.
-int attn_backend() {
-  const char* e = getenv("CTK_ATTN");
-  return e ? atoi(e) : 0;
-}
+// CTK_OPT_ATTENTION_VALU (include/ctk.h): 0 = MFMA kernels for the 64-key, 64-query and square shapes | 1: the VALU kernel everywhere.
+int attn_backend() { return ctk_opt(CTK_OPT_ATTENTION_VALU); }
 
 }  // namespace
 
@@ -1014,7 +1014,7 @@ extern "C" int ctk_attention(const ctk_attn_args* a, void* stream) {
     p.qtiles = p.bpw == 2 ? 1 : (a->n1 + 31) / 32;
     const long njobs = (long)((a->nbatch + p.bpw - 1) / p.bpw) * p.qtiles;
     CtkProfScope ps(a->q_is == 1 ? "attention_time" : "attention_vself", flops, bytes, s);
-    static const bool persistent = [] { const char* tk = getenv("CTK_ATTN_TIME"); return !(tk && atoi(tk) == 0); }();  // dev knob, read once: 0 = the non-persistent kernel
+    const bool persistent = ctk_opt(CTK_OPT_ATTENTION_TIME_PERSISTENT) != 0;  // 0 = the non-persistent kernel (bit-identical)
     if (p.bpw == 2 && !p.kmask && !p.qmask && persistent) {
       // persistent waves: 2 workgroups per CU, each wave walks over ~njobs*8/2048 (batch pair, head) jobs
       const long total = njobs * CTK_HEADS;

@@ -18,6 +18,7 @@
 // K-tiles; the per-lane pixel decode stays per tile), so the ring is idle at a tile's end and serves as the epilogue's
 // transpose scratch.
 #include "pp_common.h"
+#include "ctk_options.h"
 #include <cstdlib>
 
 namespace {
@@ -517,8 +518,8 @@ extern "C" int ctk_conv2d_sh(const void* in_sh, int32_t F, int32_t Hin, int32_t 
   snprintf(pname, sizeof(pname), "conv_pp128_%dx%d_s%d_c%d_n%d", KH, KW, stride, Cin, n_out);
   const double flops = 2.0 * M * (double)n_out * g.K;
   // 3 x 3 / stride 1 / pad 1 on tile-aligned maps: the halo kernel (input tile in LDS, nine taps read it there).  CTK_CONV_HALO=0
-  // (dev A/B knob, read once) keeps every convolution on conv_pp128_kernel.
-  static const bool halo_on = [] { const char* e = getenv("CTK_CONV_HALO"); return !(e && atoi(e) == 0); }();
+  // (dev builds only) keeps every convolution on conv_pp128_kernel.
+  const bool halo_on = CTK_DEV_KNOB("CTK_CONV_HALO", 1) != 0;
   if (halo_on && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Hout % 8 == 0 && Wout % 32 == 0 && Hout == Hin && Wout == Win) {
     const long htiles = (long)F * (Hout / 8) * (Wout / 32) * g.nblocks;
     char hname[48];
@@ -531,7 +532,7 @@ extern "C" int ctk_conv2d_sh(const void* in_sh, int32_t F, int32_t Hin, int32_t 
     return CTK_OK;
   }
   CtkProfScope ps(pname, flops, 4.0 * ((double)F * Hin * Win * Cin + (double)M * n_out), s);
-  static const bool force_ph1 = [] { const char* e = getenv("CTK_CONV_PH1"); return e && atoi(e) == 1; }();  // dev A/B knob (read once): 1 = round-3 behaviour
+  const bool force_ph1 = CTK_DEV_KNOB("CTK_CONV_PH1", 0) == 1;  // dev builds: 1 = round-3 behaviour
   hipLaunchKernelGGL((conv_pp128_kernel<32>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), 0, s, p, (int)tiles, force_ph1);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;

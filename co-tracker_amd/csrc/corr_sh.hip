@@ -30,6 +30,7 @@
 //     Footprint, C and staging are separate buffers, so nothing aliases inside the loop and a wave carries MFMA work and
 //     VALU/LDS work of two different frames between the same pair of barriers.
 #include "ctk_common.h"
+#include "ctk_options.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
 #include <cstdlib>
@@ -51,7 +52,6 @@ constexpr int C_BYTES = FROWS * CPITCH * 4;  // 21120: f32 C[pixel][q] (columns 
 constexpr int STG_BYTES1 = CTK_CORR_LD * 4;  // 9728: f32 staging row of the blended outputs
 constexpr float FSCALE = 256.0f;             // both operands are scaled by 2^8 before the f16 split
 constexpr float UNSCALE = 1.0f / 65536.0f;
-constexpr int QUADS = CTK_CORR_LD / 4;       // 608 output quads per (frame, level, point)
 constexpr int LDS1_BYTES = FP_BYTES + C_BYTES + STG_BYTES1 + TAB_BYTES;  // 80128
 static_assert(SUP_BYTES + 15 * 128 <= C_BYTES + STG_BYTES1, "the support image (prologue only) aliases C + staging");
 static_assert(2 * LDS1_BYTES <= 160 * 1024, "two workgroups per CU");
@@ -66,8 +66,7 @@ struct CorrShP {
   _Float16* out;        // [L][ncount*S][2*CTK_CORR_LD] halves
   long out_level_stride;
   int S, N, n0, ncount, tchunks;
-  int map;  // version 3: workgroup -> (point, level) dealing (dev knob CTK_CORR_MAP), see corr_volume_sh3_kernel
-  int dbg;  // dev-only bisection bits (CTK_CORR_DBG): 1 = skip the volume stores, 2 = all lanes read pixel 0 (no footprint traffic), 4 = nontemporal volume stores, 8 = no cross-frame prefetch
+  int map;  // version 3: workgroup -> (point, level) dealing (CTK_OPT_CORR_MAP), see corr_volume_sh3_kernel
 };
 
 struct FrameTab {  // per-frame tap table (LDS), 256 bytes
@@ -364,328 +363,9 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh_kernel(CorrShP p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Version 2 of the sampler (opt-in, CTK_CORR=2): one WAVE per frame, no barrier inside the frame loop, the blend on
-// MFMA as well.  An experiment that did NOT beat version 1 -- kept selectable with its measurements because the
-// counters are instructive (profiles/r01_corr_v1_v2_pmc.txt, tools/bench_corr.py):
-//   * the workgroup still owns (point, level, <= 16 frames) and splits the support patch once into the swizzled LDS
-//     image (the MFMA B operand, rows 49..63 zero), but each of its 4 waves then processes WHOLE frames
-//     (t = wave, wave + 4, ...) independently;
-//   * the 8 x 8 footprint (64 pixels = two 32-row MFMA tiles, row i = fy * 8 + fx) is read from the SH pyramid
-//     STRAIGHT into A-operand registers (lane = pixel, 16 B = 8 consecutive channels of one plane), one K-tile
-//     ahead of the MFMAs and, across frames, behind the previous frame's blend -- no LDS copy of the footprint;
-//   * C[pixel][tap q] stays in the accumulators (lane = q, registers = pixels) and becomes the B operand of a
-//     SECOND split-half MFMA that applies the bilinear blend:  D[p][q] = sum_px Wb[p][px] C[px][q], where row p of
-//     Wb holds the <= 4 corner weights of tap p.  Wb is separable, Wb[p][(fy, fx)] = Y_p[fy] * X_p[fx], and with
-//     the fixed footprint pitch the accumulator-induced k order (pixel of k-slot (ks, half, e) = 16 ks + 8 (e>>2)
-//     + 4 half + (e&3), i.e. fy = 2 ks + (e>>2), fx = 4 half + (e&3)) is known at compile time, so a lane builds
-//     its A fragment from 8 Y and 4 X values with 8 multiplies per k-step;
-//   * D (lane = q, registers = p) goes through a wave-private f32 staging row in LDS to turn into coalesced SH
-//     stores of the (h, w, i, j)-flattened volume row.
-// A footprint wider / taller than 8 (integer coordinates, where the reference's coordinate round trip floors some
-// taps to x-1) is covered by up to three more passes with the origin shifted by one pixel in which only the new
-// column / row carries weight; those passes ADD into the staging row.
-// Same values as version 1 up to f32 rounding: the weights are the reference's (ctk_tap), their products
-// wx*wy are formed in f32 exactly as ATen does, and both MFMA stages keep ~2^-21 relative accuracy per product.
-//
-// Measured (MI355X, S=16, N=6400; clocks stay at 2.3-2.4 GHz, so this is not the power cap): version 1 2.75 ms,
-// version 2 3.0 ms per launch; version 2 without any global traffic 1.65 ms.  SQ counters per frame: 1322 VALU +
-// 144 MFMA + ~250 other instructions per wave (version 1: 2270 per frame over its 4 waves).  A SIMD issues about
-// one instruction per 4 cycles whichever wave it comes from, so 9 VALU per MFMA exceeds what can hide behind a
-// 32-cycle MFMA (<= 5-6 issue slots): VALU time and MFMA time ADD (0.77 ms + 0.77 ms of 1.65 ms) instead of
-// overlapping, and at 240+ VGPRs only two waves per SIMD are left to cover the memory waits (43 % of the wave
-// cycles of the full kernel).  The splits (f32 -> hi/lo halves, 3 VALU per value for C and for Wb) are 60 % of the
-// VALU work.  Deeper prefetch (two K-tiles ahead) or 16-byte stores push the kernel over 256 VGPRs and spill.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int SUPI_KT = 64 * 128;            // bytes per K-tile of the support image: 64 rows (49 used) x 128 B
-constexpr int SUPI_BYTES = NKT * SUPI_KT;    // 32 KiB
-constexpr int STG_BYTES = CTK_CORR_LD * 4;   // f32 staging row of one wave
-constexpr float CSCALE = 1.0f / 64.0f;       // accumulator (2^16 x true C) -> 2^10 x C before the f16 split
-constexpr float WSCALE = 4096.0f;            // blend weights are split as 2^12 x w
-constexpr float DSCALE = 1.0f / 4194304.0f;  // 2^-22
-static_assert(2 * (SUPI_BYTES + 4 * STG_BYTES) <= 160 * 1024, "two workgroups per CU");
-
-typedef const __attribute__((address_space(1))) _Float16* GHalfPtr;  // explicit global pointer: a pointer that
-// travels through a local array loses its inferred address space and would be loaded with FLAT instructions,
-// which tick lgkmcnt as well and so get drained together with every LDS read
-
-struct TapRel {  // one tap along one axis, indices relative to the footprint origin
-  int r0, r1;
-  float w0, w1;
-};
-
-__global__ __launch_bounds__(256, 2) void corr_volume_sh2_kernel(CorrShP p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[SUPI_BYTES + 4 * STG_BYTES];
-  unsigned char* sup = lds;
-
-  unsigned bid = ctk_xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = bid % p.tchunks;
-  bid /= p.tchunks;
-  const int lvl = bid % CTK_LEVELS;
-  const int nl = bid / CTK_LEVELS;  // local point index
-  const int n = p.n0 + nl;
-  const int t0 = tc * TC;
-  const int nt = min(TC, p.S - t0);
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int r32 = lane & 31, half = lane >> 5;
-  constexpr long ROW_H = 2 * CTK_CORR_LD;  // halves per SH volume row
-  _Float16* out_base = p.out + (long)lvl * p.out_level_stride + ((long)nl * p.S + t0) * ROW_H;
-
-  const bool live = p.mask ? (p.mask[n] != 0) : true;
-  if (!live) {  // support features of not-yet-queried tracks are zeroed (cotracker3_online.py:493-496)
-    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long i = tid; i < (long)nt * ROW_H / 8; i += 256) reinterpret_cast<f16x8*>(out_base)[i] = z;
-    return;
-  }
-
-  const int H = p.H[lvl], W = p.W[lvl];
-  const float sx = p.sx[lvl], sy = p.sy[lvl];
-  const float inv = 1.0f / (float)(1 << lvl);  // coords / 2**i : exact
-  const _Float16* fm = p.fm[lvl];
-
-  // ---- prologue: support patch -> split, scaled, swizzled image; rows 49..63 and the staging pad columns = 0 ----
-  {
-    const float* sp = p.support[lvl] + (long)n * CTK_TAPS * CTK_C;
-    f32x4 v[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {  // float4 i = tid + 256 j of the [49][32] float4 patch
-      const int i = min(tid + 256 * j, CTK_TAPS * 32 - 1);
-      v[j] = *reinterpret_cast<const f32x4*>(sp + i * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
-      if (i < CTK_TAPS * 32) {
-        f16x4 hi, lo;
-        ctk_split4(v[j] * FSCALE, hi, lo);
-        const int kt = c4 >> 3, k8 = (c4 & 7) >> 1, sub = c4 & 1;  // K-tile, 16-byte chunk inside the plane, half of it
-        const int fs = (row >> 1) & 7;
-        unsigned char* base = sup + kt * SUPI_KT + row * 128 + sub * 8;
-        *reinterpret_cast<f16x4*>(base + ((k8 ^ fs) << 4)) = hi;
-        *reinterpret_cast<f16x4*>(base + (((4 + k8) ^ fs) << 4)) = lo;
-      }
-    }
-    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < NKT * 15 * 8; i += 256) {  // 16-byte chunks of rows 49..63 of every K-tile
-      const int kt = i / 120, r = i - kt * 120;
-      *reinterpret_cast<f16x8*>(sup + kt * SUPI_KT + (CTK_TAPS + (r >> 3)) * 128 + ((r & 7) << 4)) = z;
-    }
-  }
-  float* stg = reinterpret_cast<float*>(lds + SUPI_BYTES + wave * STG_BYTES);
-  if (lane < CTK_CORR_LD - CTK_CORR_K) stg[CTK_CORR_K + lane] = 0.0f;  // K padding columns of corr_mlp.fc1
-  __syncthreads();
-
-  // B-fragment addressing (as version 1): chunk c = plane*4 + s*2 + half of row r sits at r*128 + ((c ^ f(r)) << 4)
-  const int fsw = (r32 >> 1) & 7;
-  int coff[2][2];  // [k-step s][plane]
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) coff[s][pl] = ((pl * 4 + s * 2 + half) ^ fsw) << 4;
-  const unsigned char* sup_frag = sup + r32 * 128;
-
-  // my two blend rows (taps): p = 32 pt + r32 -> (x tap p / 7, y tap p % 7); rows >= 49 duplicate tap 48, never stored
-  int bhx[2], bwy[2];
-#pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int pp = min(32 * pt + r32, CTK_TAPS - 1);
-    bhx[pt] = pp / 7;  // first 7-index = x offset, second = y (cotracker3_online.py:102-104)
-    bwy[pt] = pp - 7 * bhx[pt];
-  }
-
-  // geometry of a frame (wave-uniform: one point, one frame per wave -> SGPRs): footprint origin and size
-  struct Org {
-    int xb, yb, fw, fh;
-  };
-  auto origin = [&](float cx, float cy) {
-    const CtkTap ax = ctk_tap(__fadd_rn(cx, -3.0f), W, sx), bx = ctk_tap(__fadd_rn(cx, 3.0f), W, sx);
-    const CtkTap ay = ctk_tap(__fadd_rn(cy, -3.0f), H, sy), by = ctk_tap(__fadd_rn(cy, 3.0f), H, sy);
-    Org o;
-    o.xb = __builtin_amdgcn_readfirstlane(ax.i0);
-    o.yb = __builtin_amdgcn_readfirstlane(ay.i0);
-    o.fw = __builtin_amdgcn_readfirstlane(bx.i1 - ax.i0 + 1);
-    o.fh = __builtin_amdgcn_readfirstlane(by.i1 - ay.i0 + 1);
-    return o;
-  };
-  // A-operand source rows of my two pixels (row tile rt: fy = 4 rt + (r32 >> 3), fx = r32 & 7) for a tile origin;
-  // pixels outside the image (footprints clipped at a border) re-read the border pixel: they carry zero weight
-  auto pixel_ptrs = [&](int tl, int ox, int oy, GHalfPtr (&pa)[2]) {
-    const int x = min(ox + (r32 & 7), W - 1);
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const int y = min(oy + 4 * rt + (r32 >> 3), H - 1);
-      pa[rt] = (GHalfPtr)fm + (((long)(t0 + tl) * H + y) * W + x) * (2 * CTK_C) + half * 8;
-      if (p.dbg & 2) pa[rt] = (GHalfPtr)fm + half * 8;
-    }
-  };
-  // one K-tile of A fragments: [rt][s*2 + plane]
-  auto load_a = [&](const GHalfPtr (&pa)[2], int kt, f16x8 (&a)[2][4]) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) a[rt][s * 2 + pl] = *reinterpret_cast<const __attribute__((address_space(1))) f16x8*>(pa[rt] + kt * 64 + pl * 32 + s * 16);
-  };
-  auto load_xy = [&](int tl, float& x, float& y) {  // raw coordinates of frame tl (clamped: unused past the chunk)
-    const float* cp = p.coords + ((long)(t0 + min(tl, nt - 1)) * p.N + n) * 2;
-    x = cp[0];
-    y = cp[1];
-  };
-
-  if (wave >= nt) return;
-  // Software pipeline: inside a frame the A fragments run one K-tile ahead of the MFMAs; a frame's first K-tile is
-  // requested before the PREVIOUS frame's blend and its coordinates two frames ahead (two waves per SIMD cover
-  // the rest of the memory latency).
-  float rx, ry, rxn, ryn;  // raw coordinates of this / the next frame of this wave
-  load_xy(wave, rx, ry);
-  load_xy(wave + 4, rxn, ryn);
-  GHalfPtr pa[2];
-  f16x8 anext[2][4];
-  {
-    const Org o = origin(__fmul_rn(rx, inv), __fmul_rn(ry, inv));
-    pixel_ptrs(wave, o.xb, o.yb, pa);
-    load_a(pa, 0, anext);
-  }
-  for (int tl = wave; tl < nt; tl += 4) {
-    float rxnn, rynn;
-    load_xy(tl + 8, rxnn, rynn);
-    const float cx = __fmul_rn(rx, inv), cy = __fmul_rn(ry, inv);
-    const Org o = origin(cx, cy);
-    const int npx = o.fw > 8 ? 2 : 1, npy = o.fh > 8 ? 2 : 1;  // > 1 only at (near-)integer coordinates
-    // the previous frame's staging reads are complete before this frame's first staging write
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // One pass = one 8 x 8 tile of the footprint with origin (xb + px, yb + py); D of an extra pass is ADDED to
-    // the staging row, so no accumulator is live across stage 1.
-    for (int py = 0; py < npy; ++py)
-      for (int px = 0; px < npx; ++px) {
-        const bool first = (px | py) == 0, last = (px == npx - 1) && (py == npy - 1);
-        if (!first || (p.dbg & 8)) {  // rare extra pass: a shifted origin stays inside the image (xb + 8 is a tap corner)
-          pixel_ptrs(tl, o.xb + px, o.yb + py, pa);
-          load_a(pa, 0, anext);
-        }
-        // ---- stage 1: C[pixel][q] = footprint . support^T, K = 128 in 4 K-tiles ----
-        f32x16 cacc[2][2];  // [rt][ct]
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cacc[rt][ct][e] = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-          f16x8 acur[2][4];
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acur[rt][i] = anext[rt][i];
-          if (kt + 1 < NKT) load_a(pa, kt + 1, anext);
-          __builtin_amdgcn_sched_barrier(0);  // keep the loads ONE K-tile ahead (hipcc would hoist all of them: spills)
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-              const f16x8 bh = *reinterpret_cast<const f16x8*>(sup_frag + kt * SUPI_KT + ct * 4096 + coff[s][0]);
-              const f16x8 bl = *reinterpret_cast<const f16x8*>(sup_frag + kt * SUPI_KT + ct * 4096 + coff[s][1]);
-#pragma unroll
-              for (int rt = 0; rt < 2; ++rt) cacc[rt][ct] = ctk_mma3(acur[rt][s * 2], acur[rt][s * 2 + 1], bh, bl, cacc[rt][ct]);
-            }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        // next frame's first K-tile: in flight behind this frame's blend and stores
-        if (last && tl + 4 < nt && !(p.dbg & 8)) {
-          const Org on = origin(__fmul_rn(rxn, inv), __fmul_rn(ryn, inv));
-          pixel_ptrs(tl + 4, on.xb, on.yb, pa);
-          load_a(pa, 0, anext);
-        }
-        // my taps relative to the footprint origin (computed here, not carried across stage 1)
-        TapRel tx[2], ty[2];
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-          const CtkTap a = ctk_tap(__fadd_rn(cx, (float)(bhx[pt] - 3)), W, sx);
-          const CtkTap b = ctk_tap(__fadd_rn(cy, (float)(bwy[pt] - 3)), H, sy);
-          tx[pt].r0 = a.i0 - o.xb; tx[pt].r1 = a.i1 - o.xb; tx[pt].w0 = a.w0; tx[pt].w1 = a.w1;
-          ty[pt].r0 = b.i0 - o.yb; ty[pt].r1 = b.i1 - o.yb; ty[pt].w0 = b.w0; ty[pt].w1 = b.w1;
-        }
-        // ---- stage 2: C -> B fragments (k = pixel in accumulator order), D = Wb . C ----
-        f16x8 ch[2][4], cl[2][4];  // [ct][ks]
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const int rt = ks >> 1, b = 8 * (ks & 1);
-            const f32x4 a = {cacc[rt][ct][b] * CSCALE, cacc[rt][ct][b + 1] * CSCALE, cacc[rt][ct][b + 2] * CSCALE, cacc[rt][ct][b + 3] * CSCALE};
-            const f32x4 c = {cacc[rt][ct][b + 4] * CSCALE, cacc[rt][ct][b + 5] * CSCALE, cacc[rt][ct][b + 6] * CSCALE, cacc[rt][ct][b + 7] * CSCALE};
-            ctk_split8(a, c, ch[ct][ks], cl[ct][ks]);
-          }
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-          // X_p over my 4 columns fx = 4 half + j, Y_p over the 8 rows; in an extra pass only the new column / row counts
-          float xs[4], ys[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int fx = 4 * half + j, fr = fx + px;
-            const float w = (fr == tx[pt].r0 ? tx[pt].w0 : 0.0f) + (fr == tx[pt].r1 ? tx[pt].w1 : 0.0f);
-            xs[j] = (px == 0 || fx == 7) ? w * WSCALE : 0.0f;
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int fr = i + py;
-            const float w = (fr == ty[pt].r0 ? ty[pt].w0 : 0.0f) + (fr == ty[pt].r1 ? ty[pt].w1 : 0.0f);
-            ys[i] = (py == 0 || i == 7) ? w : 0.0f;
-          }
-          f32x16 dacc[2];  // [ct]: lane = q, registers = p
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dacc[ct][e] = 0.0f;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const float y0 = ys[2 * ks], y1 = ys[2 * ks + 1];
-            const f32x4 wa = {xs[0] * y0, xs[1] * y0, xs[2] * y0, xs[3] * y0};
-            const f32x4 wc = {xs[0] * y1, xs[1] * y1, xs[2] * y1, xs[3] * y1};
-            f16x8 wh, wl;
-            ctk_split8(wa, wc, wh, wl);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) dacc[ct] = ctk_mma3(wh, wl, ch[ct][ks], cl[ct][ks], dacc[ct]);
-          }
-          // D -> wave-private staging row [p*49 + q] (f32); an extra pass adds to it
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const int q = 32 * ct + r32;
-            float* d0 = stg + (32 * pt + 4 * half) * CTK_TAPS + q;
-            if (first) {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const int pr = 8 * (e >> 2) + (e & 3);  // row offset of register e: p = 32 pt + 4 half + pr
-                if (32 * pt + 4 * half + pr < CTK_TAPS && q < CTK_TAPS) d0[pr * CTK_TAPS] = dacc[ct][e] * DSCALE;
-              }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const int pr = 8 * (e >> 2) + (e & 3);
-                if (32 * pt + 4 * half + pr < CTK_TAPS && q < CTK_TAPS) d0[pr * CTK_TAPS] += dacc[ct][e] * DSCALE;
-              }
-            }
-          }
-        }
-      }
-    // ---- staging row -> coalesced SH stores ----
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS is in-order per wave: every lane's writes have landed
-    _Float16* orow = out_base + (long)tl * ROW_H;
-    if (!(p.dbg & 1))
-    for (int qd = lane; qd < QUADS; qd += 64) {
-      f16x4 hi, lo;
-      ctk_split4(reinterpret_cast<const f32x4*>(stg)[qd], hi, lo);
-      _Float16* dst = orow + ctk_sh_col(qd * 4);
-      *reinterpret_cast<f16x4*>(dst) = hi;
-      *reinterpret_cast<f16x4*>(dst + 32) = lo;
-    }
-    rx = rxn; ry = ryn;
-    rxn = rxnn; ryn = rynn;
-  }
-}
+// (Version 2 of the sampler -- one WAVE per frame, the blend as a second MFMA -- lived here in rounds 1-5: parity-green, 2.98 ms per
+// launch against 2.52 / 2.30 ms for versions 1 / 3; its SQ-counter post-mortem is in profiles/r01_corr_v1_v2_pmc.txt and the code in
+// git show 360f4f4:co-tracker_amd/csrc/corr_sh.hip.  Round 6 removed it from the library.)
 
 // ---------------------------------------------------------------------------------------------------------
 // Version 3 (round 5): the footprint never touches LDS and the frame loop has ONE barrier per frame.
@@ -711,7 +391,7 @@ constexpr int LDS3_BYTES = 2 * C_BYTES + 2 * STG_BYTES1 + TAB_BYTES;  // 65920
 static_assert(SUP_BYTES + 15 * 128 <= 2 * C_BYTES, "the support image (prologue only) aliases the C tables");
 static_assert(2 * LDS3_BYTES <= 160 * 1024, "two workgroups per CU");
 
-// DBG (dev-only bisection, CTK_CORR_DBG): 1 = no volume stores, 2 = every lane reads pixel 0 (no footprint traffic), 16 = no MFMAs,
+// DBG (bisection bits; instantiated with DBG != 0 only in dev builds, make dev + CTK_CORR_DBG): 1 = no volume stores, 2 = every lane reads pixel 0 (no footprint traffic), 16 = no MFMAs,
 // 32 = no blend, 64 = no store phase at all (no staging reads, no splits)
 template <int DBG>
 __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
@@ -1056,29 +736,30 @@ int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh
   const double units = (double)ncount * a->S * CTK_LEVELS;
   CtkProfScope ps("corr_volume_sh", units * 2.0 * 49 * 49 * 128,
                   units * (64.0 * 128 * 4 + 49.0 * 128 * 4 / a->S + 2.0 + 2401.0 * 4), s);
-  // Dev knobs, read per call: CTK_CORR selects the kernel version (default 3), CTK_CORR_DBG = bisection bits of versions 2 / 3.
-  // Measured on MI355X at the C3 window (tools/bench_corr.py, round 5): version 1 2.52-2.62 ms, version 2 2.98 ms,
-  // version 3 2.39-2.48 ms per launch.
-  const char* dbg = getenv("CTK_CORR_DBG");
-  p.dbg = dbg ? atoi(dbg) : 0;
-  // Workgroup -> (point, level) dealing of version 3.  Default 3 = level-major (consecutive workgroup ids, which the XCD remap
-  // keeps on one XCD, are consecutive points of ONE level: a grid query's neighbours share 60-90 % of their footprints, so the
-  // second one finds the lines in L1 / L2): 2.47 -> 2.25 ms per launch at the C3 window; 0 = point-major (levels innermost, the
-  // order of versions 1 / 2), 1 / 2 = point pairs, 4 = blocks of 16 points (profiles/r05_sampler_v3_bisect.txt).
-  const char* mp = getenv("CTK_CORR_MAP");
-  p.map = mp ? atoi(mp) : 3;
-  const char* ver = getenv("CTK_CORR");
-  const int v = ver ? atoi(ver) : 3;  // version 3 since round 5 (1 = the two-barrier LDS-footprint kernel, 2 = the wave-per-frame experiment)
-  if (v == 2) hipLaunchKernelGGL(corr_volume_sh2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  else if (v == 3) {
-    switch (p.dbg) {
+  // CTK_OPT_CORR_VERSION (include/ctk.h): 3 = wave-owned footprint rows (default since round 5), 1 = the two-barrier LDS-footprint
+  // kernel.  Measured on MI355X at the C3 window (tools/bench_corr.py, round 5): version 1 2.52-2.62 ms, version 3 2.25-2.48 ms.
+  // CTK_OPT_CORR_MAP: workgroup -> (point, level) dealing of version 3.  Default 3 = level-major (consecutive workgroup ids, which
+  // the XCD remap keeps on one XCD, are consecutive points of ONE level: a grid query's neighbours share 60-90 % of their footprints,
+  // so the second one finds the lines in L1 / L2): 2.47 -> 2.25 ms per launch at the C3 window; 0 = point-major (levels innermost,
+  // the order of version 1), 1 / 2 = point pairs, 4 = blocks of 16 points (profiles/r05_sampler_v3_bisect.txt).
+  p.map = ctk_opt(CTK_OPT_CORR_MAP);
+  const int v = ctk_opt(CTK_OPT_CORR_VERSION);
+  if (v == 3) {
+#ifdef CTK_DEV
+    // dev build only (make dev): CTK_CORR_DBG = bisection bits of version 3 (they change the RESULT: tools/bench_corr.py)
+    static const int dbg = [] { const char* e = getenv("CTK_CORR_DBG"); return e ? atoi(e) : 0; }();
+    switch (dbg) {
 #define CTK_SH3(D) case D: hipLaunchKernelGGL(corr_volume_sh3_kernel<D>, dim3((unsigned)blocks), dim3(256), 0, s, p); break
       CTK_SH3(1); CTK_SH3(2); CTK_SH3(3); CTK_SH3(16); CTK_SH3(32); CTK_SH3(48); CTK_SH3(64); CTK_SH3(112);
 #undef CTK_SH3
       default: hipLaunchKernelGGL(corr_volume_sh3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
+#else
+    hipLaunchKernelGGL(corr_volume_sh3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+#endif
+  } else {
+    hipLaunchKernelGGL(corr_volume_sh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   }
-  else hipLaunchKernelGGL(corr_volume_sh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }

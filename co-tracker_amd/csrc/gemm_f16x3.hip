@@ -21,6 +21,7 @@
 //    40 halves (80 B): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank groups.
 //    Double-buffered LDS, one barrier per K-tile, next tile's global loads issued before the MFMAs.
 #include "ctk_common.h"
+#include "ctk_options.h"
 #include "ctk_profile.h"
 #include "gemm_params.h"
 #include <cstdio>
@@ -533,8 +534,11 @@ __global__ __launch_bounds__(256) void gemm_sh_deep64_kernel(CtkGemmP g) {
     st = (st + 1 == NS) ? 0 : st + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the duplicate tail requests
-  // (compile-time epilogues for the six Linear flavours: the same arithmetic, bit for bit, as gemm_sh_kernel's and the
-  // persistent kernels' -- the tail rows of a split launch must not differ from the rows the persistent kernel wrote)
+  // (compile-time epilogues for the six Linear flavours: the same arithmetic as gemm_sh_kernel's and the persistent kernels',
+  // so that the tail rows of a split launch carry the bits the persistent kernel would have written -- EXCEPT for the "+ residual"
+  // Linears (to_out, mlp.fc2), where gemm_pp192_kernel adds residual * s into the accumulators during K-tiles 1..7 and this
+  // epilogue adds the residual after unscale and bias: identical up to ONE rounding (tests/test_gpu_gemm_pp.py allows 4e-6
+  // relative), so a row's last bit there depends on which side of the cut it falls, i.e. on M and the CU count)
   if (EPI == EPI_GENERIC) gemm_epilogue<1, 1>(g, acc, m0 + wm * 32, n0 + wn * 32, r32, half, bz);
   else gemm_epilogue_c<1, 1, EPI>(g, acc, m0 + wm * 32, n0 + wn * 32, r32, half, bz);
 }
@@ -586,13 +590,10 @@ __global__ void weight_pack_kernel(const float* W, long ldw, int N, int K, const
 }  // namespace
 
 namespace {
-// Dev knob (read per call): CTK_GEMM_TILE = 0 auto (128x128, 2 blocks/CU) | 2 force 256x128 (8 waves, 1 block/CU,
+// Dev-build knob (read once; the release library always takes 0): CTK_GEMM_TILE = 0 auto (128x128, 2 blocks/CU) | 2 force 256x128 (8 waves, 1 block/CU,
 // 2 LDS stages) | 3 force 256x128 with 3 LDS stages (counted vmcnt + raw barrier) | 4 use 128x384 for N = 384 | 5 64x128 tile (3 workgroups per CU) | 6 256x256 tile for every N % 256 == 0 launch |
 // 1 128x128 everywhere (no 256x256).
-int gemm_tile_pref() {
-  const char* e = getenv("CTK_GEMM_TILE");
-  return e ? atoi(e) : 0;
-}
+int gemm_tile_pref() { return (int)CTK_DEV_KNOB("CTK_GEMM_TILE", 0); }
 
 template <typename K>
 int launch_with_lds(K kernel, unsigned blocks, unsigned threads, size_t lds_bytes, const CtkGemmP& g, hipStream_t s) {
@@ -609,7 +610,7 @@ int ctk_launch_gemm_sh64(CtkGemmP& g, double flops, double bytes, hipStream_t s)
   char pname[32];
   snprintf(pname, sizeof(pname), "gemm_sh_64_k%d_n%d", g.K, g.N);
   CtkProfScope ps(pname, flops, bytes, s);
-  static const int deep = [] { const char* e = getenv("CTK_GEMM_DEEP64"); return e ? atoi(e) : 4; }();  // dev knob, read once: 0 = 2-stage kernel, 4 / 8 = stages
+  const int deep = (int)CTK_DEV_KNOB("CTK_GEMM_DEEP64", 4);  // dev builds: 0 = 2-stage kernel, 4 / 8 = stages
   const dim3 grid((unsigned)((long)g.mblocks * g.nblocks * g.batch));
   if (deep >= 8) hipLaunchKernelGGL((gemm_sh_deep64_kernel<8>), grid, dim3(256), 0, s, g);
   else if (deep >= 4) {
@@ -646,7 +647,7 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
   }
   const long blocks128 = (long)((g.M + 127) / 128) * (g.N / 128) * g.batch;
   // 128 x 128 tiles once they fill most of the 512 resident slots, 64 x 64 below (CTK_GEMM_BIG_MIN overrides the threshold)
-  static const long big_min = [] { const char* e = getenv("CTK_GEMM_BIG_MIN"); return e ? atol(e) : 384L; }();
+  const long big_min = CTK_DEV_KNOB("CTK_GEMM_BIG_MIN", 384L);
   const bool big = (g.N % 128) == 0 && blocks128 >= big_min;
   if (g.a_split) {
     const int pref = gemm_tile_pref();
@@ -744,8 +745,7 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
     if (t64) hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 1, 2, 2, E>), grid, blk, 0, s, g); \
     else hipLaunchKernelGGL((gemm_sh_kernel<2, 2, 2, 2, 2, E>), grid, blk, 0, s, g);     \
   } while (0)
-      const char* ge = getenv("CTK_GEMM_EPI");  // dev knob: CTK_GEMM_EPI=0 forces the generic epilogue
-      if (ge && atoi(ge) == 0) CTK_SH128(EPI_GENERIC);
+      if (CTK_DEV_KNOB("CTK_GEMM_EPI", 1) == 0) CTK_SH128(EPI_GENERIC);  // dev builds: CTK_GEMM_EPI=0 forces the generic epilogue
       else switch (code) {
         case epi_code(CTK_ACT_GELU_ERF, false, true, false, true): CTK_SH128(epi_code(CTK_ACT_GELU_ERF, false, true, false, true)); break;    // corr_mlp.fc1
         case epi_code(CTK_ACT_NONE, false, true, false, true): CTK_SH128(epi_code(CTK_ACT_NONE, false, true, false, true)); break;            // corr_mlp.fc2 -> x

@@ -57,7 +57,6 @@ struct CtkGemmP {
   int batch; long a_bs; long c_bs;  // batch strides, in elements of the respective format (floats / halves)
   int a_split, c_split;
   int mblocks, nblocks;
-  void* sk;                         // gemm_pp.hip: stream-K scratch (partials + flags) or null; set by the launcher
 };
 
 // gemm_f16x3.hip
@@ -65,26 +64,3 @@ int ctk_launch_gemm_f16x3(CtkGemmP& g, double flops, double bytes, hipStream_t s
 int ctk_launch_gemm_sh64(CtkGemmP& g, double flops, double bytes, hipStream_t s);  // 64 x 64 tiles (SH operands)
 // gemm_pp.hip: persistent ping-pong kernels; returns -1 when the shape is not theirs (caller falls back)
 int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s);
-// Stream-K scratch of the persistent kernels: the entry points that own a workspace lend a piece of it for the duration of
-// the call (thread-local; zeroes the flags on `s`).  Only launches on that stream use it; without one the kernels deal whole
-// tiles in rounds.
-// Limits the workgroups of the persistent GEMMs launched by this thread while in scope (0 = no limit): a persistent workgroup owns
-// its CU's whole LDS, so a launch on every CU locks everything else out of the chip for its whole duration; api.hip's overlap
-// mode 8 leaves some CUs to the small launches of the virtual-track chain.  Results do not depend on the grid size.
-struct CtkPPCuLimit {
-  explicit CtkPPCuLimit(int n);
-  ~CtkPPCuLimit();
-  CtkPPCuLimit(const CtkPPCuLimit&) = delete;
-  CtkPPCuLimit& operator=(const CtkPPCuLimit&) = delete;
-  int prev_;
-};
-size_t ctk_pp_scratch_bytes();
-size_t ctk_pp_scratch_bytes_if_enabled();
-struct CtkPPScratchScope {
-  CtkPPScratchScope(void* mem, size_t bytes, hipStream_t s);
-  ~CtkPPScratchScope();
-  CtkPPScratchScope(const CtkPPScratchScope&) = delete;
-  CtkPPScratchScope& operator=(const CtkPPScratchScope&) = delete;
- private:
-  void* prev_mem_; size_t prev_bytes_; hipStream_t prev_stream_;
-};

@@ -21,10 +21,12 @@
 //     twice instead of three times).
 // Same numerics as gemm_f16x3.hip (3 x v_mfma_f32_32x32x16_f16 per product, small terms first within a k-step).
 #include "pp_common.h"
+#include "ctk_options.h"
 #include <type_traits>
 
 namespace {
 
+#ifdef CTK_DEV
 // ---- wave timeline (DBG kernels only, ctk_gemm_pp_mode bit 6): the first PP_TRACE_WGS workgroups stamp s_memtime at the start of
 // every MFMA phase (right behind the lgkmcnt(0) wait that is there anyway), before and after every epilogue, into the 8 KiB of LDS
 // no kernel uses, and dump them at exit; ctk_debug_pp_trace() copies them out (tools/gemm_lab trace).  The stamp itself waits
@@ -41,7 +43,7 @@ __device__ __forceinline__ void pp_trace_clocks(unsigned char* dst, const int la
     reinterpret_cast<unsigned long long*>(dst)[1] = b;
   }
 }
-// Every launch (production kernels too): wave 0 of workgroup 0 leaves (s_memtime, s_memrealtime) at its start and end in g_pp_clock --
+// Every launch of a DEV build (make dev): wave 0 of workgroup 0 leaves (s_memtime, s_memrealtime) at its start and end in g_pp_clock --
 // two scalar loads and two 16-byte stores per launch.  s_memrealtime ticks at 100 MHz, so the pair gives the shader clock the
 // launch actually ran at (ctk_debug_pp_clock; tools/gemm_lab clock): the GEMMs are power-capped, and by how much is a number.
 __device__ unsigned long long g_pp_clock[4];
@@ -79,43 +81,31 @@ __device__ __forceinline__ void pp_clock_probe(const int which, const int tid) {
         g_pp_trace[((long)blockIdx.x * 8 + wave) * PP_TRACE_STAMPS + i] = *reinterpret_cast<unsigned long long*>(lds + PP_TRACE_OFF + wave * 1024 + i * 8); \
     }                                                                                                                   \
   } while (0)
+#else  // release build: no instruments, no device-side globals written by production launches
+#define PP_STAMP() do {} while (0)
+#define PP_TRACE_INIT() do {} while (0)
+#define PP_TRACE_DUMP() do {} while (0)
+__device__ __forceinline__ void pp_clock_probe(const int, const int) {}
+#endif
 
 // ---- tile walk -----------------------------------------------------------------------------------
-// Two ways to deal the tiles to the G persistent workgroups:
-//  * rounds (no scratch memory): in round r the G (or fewer) tiles [r*G, r*G + n_r) are dealt so that XCD x (workgroup b sits
-//    on XCD b % 8) gets a contiguous run of logical tiles (neighbours share A rows / W in its L2).  800 tiles on 256 CUs
-//    (every N = 384 Linear of the model at C3) are then FOUR rounds with the last one 1/8 full: 22 % of the launch idles;
-//  * stream-K (CtkGemmP::sk != null): the tiles' K-tiles form one stream of tiles * KT units and workgroup c (logical index,
-//    XCD-contiguous) takes units [c*UT/G, (c+1)*UT/G) -- whole tiles in the middle, the TAIL K-tiles of a tile at its start
-//    and the HEAD K-tiles of a tile at its end (UT/G >= KT, so a tile is shared by at most two workgroups).  The workgroup
-//    that starts inside a tile computes its part first, stores the raw accumulators to its scratch slot and raises one flag
-//    per wave; its logical predecessor reaches the head part of that tile last, adds the stored part in a fixed order
-//    (head + tail: deterministic) and runs the normal epilogue.  Nobody waits for anything produced later than the first
-//    segment of another workgroup, and all G <= #CUs workgroups are resident (one per CU: PP_LDS_ALL), so the spin cannot
-//    deadlock.  The partial costs 192-256 KiB of stores and loads per workgroup against 7/8 of a tile time saved.
-//    MEASURED (tools/gemm_lab quant, profiles/r03_gemm_lab_streamk.txt): the last round is cheaper than it looks -- 32 workgroups
-//    alone on the chip run at boost clocks without contention, mlp.fc2 takes 350 us for 768 tiles, 414 us for 800 (+64, not
-//    +117) and 448 us for 1024 -- so the prize is 12 % of mlp.fc2 and 15 % of the K = 384 Linears at most, of which the
-//    exchange (~20 us: cache-bypassing stores, the consumer's exposed load latency) leaves -5 % for mlp.fc2 (414 -> 394 us)
-//    and nothing for K = 384 (115 -> 118 us).  That is ~0.8 % of a C3 step, below the box-to-box spread of the benchmark,
-//    and it brings a spin-wait into the hottest kernels: OFF unless ctk_gemm_pp_mode bit 4 is set (tests/test_gpu_gemm_pp.py
-//    keeps it correct).
-constexpr int PP_SK_FLAG_BYTES = 16384;    // 8 flags x up to 512 workgroups
-constexpr long PP_SK_SLOT_MAX = 262144;    // 256 x 256 f32 accumulators
-
+// The tiles are dealt to the G persistent workgroups in rounds: in round r the G (or fewer) tiles [r*G, r*G + n_r) are dealt so
+// that XCD x (workgroup b sits on XCD b % 8) gets a contiguous run of logical tiles (neighbours share A rows / W in its L2).
+// 800 tiles on 256 CUs (every N = 384 Linear of the model at C3) would be FOUR rounds with the last one 1/8 full; the launcher's
+// tail split (ctk_launch_gemm_pp) hands such a last round to the 64 x 64-tile kernel instead.  A stream-K walk (the tiles' K ranges
+// dealt as one stream, partial tiles exchanged through cache-bypassing stores and per-wave flags) lived here in rounds 3-5, off by
+// default: it won 5 % on mlp.fc2 only (profiles/r03_gemm_lab_streamk.txt) and brought a spin-wait into the hottest kernels;
+// round 6 removed it (git show 360f4f4:co-tracker_amd/csrc/gemm_pp.hip has the code).
 struct PPTile {
   const unsigned char* a;  // A rows of the tile, K-tile 0 (bytes)
   const unsigned char* w;  // W rows of the tile, K-tile 0
   int m0, n0, bz;
   unsigned lim;            // last valid row inside the tile (rows beyond M are clamped, never stored)
-  int kb, ke;              // K-tiles [kb, ke) of this tile are mine
+  int kb, ke;              // K-tiles [kb, ke) = [0, KT)
 };
 
 struct PPWalk {
   int tiles_total, KT;
-  int sk;                                 // stream-K walk
-  int t_first, kb_first, t_last, ke_last;  // stream-K: my tiles, where the first starts and the last ends
-  int slot;                                // my logical workgroup index
 };
 
 template <int BM, int BN>
@@ -131,33 +121,11 @@ __device__ __forceinline__ void pp_tile_at(const CtkGemmP& g, unsigned tile, con
   t.lim = (unsigned)min(BM - 1, g.M - 1 - t.m0);
 }
 
-__device__ __forceinline__ PPWalk pp_walk_init(const CtkGemmP& g, const int tiles_total, const int KT, const bool sk_ok) {
-  PPWalk w;
-  w.tiles_total = tiles_total;
-  w.KT = KT;
-  w.sk = sk_ok && g.sk != nullptr;
-  const int G = gridDim.x;
-  w.slot = (int)ctk_xcd_remap(blockIdx.x, G);
-  const long UT = (long)tiles_total * KT;
-  const long u0 = UT * w.slot / G, u1 = UT * (w.slot + 1) / G;
-  w.t_first = (int)(u0 / KT);
-  w.kb_first = (int)(u0 - (long)w.t_first * KT);
-  w.t_last = (int)((u1 - 1) / KT);
-  w.ke_last = (int)(u1 - (long)w.t_last * KT);
-  return w;
-}
+__device__ __forceinline__ PPWalk pp_walk_init(const int tiles_total, const int KT) { return PPWalk{tiles_total, KT}; }
 
 // q-th tile of this workgroup's walk
 template <int BM, int BN>
 __device__ __forceinline__ bool pp_tile(const CtkGemmP& g, const PPWalk& w, int q, PPTile& t) {
-  if (w.sk) {
-    const int ti = w.t_first + q;
-    if (ti > w.t_last) return false;
-    pp_tile_at<BM, BN>(g, (unsigned)ti, w.KT, t);
-    t.kb = q == 0 ? w.kb_first : 0;
-    t.ke = ti == w.t_last ? w.ke_last : w.KT;
-    return true;
-  }
   const int G = gridDim.x, b = blockIdx.x;
   const int first = q * G;
   if (first >= w.tiles_total) return false;
@@ -201,53 +169,6 @@ __device__ __forceinline__ void pp_cursor_next(const CtkGemmP& g, const PPWalk& 
   }
 }
 
-// ---- stream-K partials ---------------------------------------------------------------------------
-// Scratch layout: [PP_SK_FLAG_BYTES of flags: 8 per workgroup, one per wave][G slots of PP_SK_SLOT_MAX bytes].  A slot holds
-// the partial TILE, row-major f32 with a pitch of BN floats and already multiplied by 1/s (no bias): it is written by the
-// ordinary epilogue (pp_epilogue_io routed to the slot) and added by the ordinary epilogue of the owner.  Wave w of the
-// consumer reads exactly the elements wave w of the producer wrote (same wave tile), so each wave has its own flag and no
-// workgroup barrier is needed in the epilogue.  Only the kernels whose epilogue is linear with an f32 output take part.
-// (round 5: not the "+ residual" Linears any more -- their tiles must start at K-tile 0, where the residual rides on the first
-// K-tiles (gemm_pp192_kernel); the tail split of ctk_launch_gemm_pp gives them what stream-K gave, without a spin-wait)
-constexpr bool pp_sk_epi(int EPI) { return (EPI & 3) == 0 && (EPI & 4) == 0 && (EPI & 8) == 0 && (EPI & 16) == 0 && (EPI & 32) != 0; }
-
-__device__ __forceinline__ unsigned char* pp_sk_slot(const CtkGemmP& g, const int slot) {
-  return static_cast<unsigned char*>(g.sk) + PP_SK_FLAG_BYTES + (long)slot * PP_SK_SLOT_MAX;
-}
-__device__ __forceinline__ int* pp_sk_flag(const CtkGemmP& g, const int slot, const int wave) { return static_cast<int*>(g.sk) + slot * 8 + wave; }
-
-// Epilogue of tile `done` under the walk: routes the output (see PPEpiIO), waits for / raises the flags.
-template <int EPI, int BM, int BN, int MI, int NI, class RowOf, class ColOf>
-__device__ __forceinline__ void pp_walk_epilogue(const CtkGemmP& g, const PPWalk& w, const PPTile& done, f32x16 (&acc)[MI][NI], const int lane, const int wave,
-                                                 const float unscale, const float* bias_lds, unsigned char* scratch,
-                                                 RowOf row_of, ColOf col_of, const bool no_store) {
-  if (!pp_sk_epi(EPI)) {
-    pp_epilogue<EPI, MI, NI>(g, acc, lane, done.bz, unscale, bias_lds, scratch, row_of, col_of, no_store);
-    return;
-  }
-  const bool part = done.kb > 0;          // tail K-tiles of a tile my logical predecessor finishes: result -> my slot
-  const bool fix = done.ke < w.KT;        // head K-tiles of a tile whose tail my logical successor computed first
-  const long tile_off = ((long)done.m0 * BN + done.n0) * 4;  // row_of / col_of are matrix coordinates: slots are addressed through them
-  PPEpiIO io;
-  io.c = part ? pp_sk_slot(g, w.slot) - tile_off : static_cast<unsigned char*>(g.C) + (long)done.bz * g.c_bs * 4;
-  io.ldc = part ? BN : g.ldc;
-  io.M = part ? done.m0 + BM : g.M;
-  io.add = fix ? pp_sk_slot(g, w.slot + 1) - tile_off : nullptr;
-  io.add_ld = BN;
-  io.bias_scale = part ? 0.0f : 1.0f;
-  io.through = part;
-  if (fix) {  // (relaxed system-scope poll = a load that misses every cache; the tile loads behind it bypass the caches too)
-    int* flag = pp_sk_flag(g, w.slot + 1, wave);
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) __builtin_amdgcn_s_sleep(8);
-  }
-  pp_epilogue_io<EPI, MI, NI>(g, io, acc, lane, unscale, bias_lds, scratch, row_of, col_of, no_store);
-  if (part) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every write-through store of this wave has been acknowledged
-    if (lane == 0) __hip_atomic_store(pp_sk_flag(g, w.slot, wave), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (fix && lane == 0) __hip_atomic_store(pp_sk_flag(g, w.slot + 1, wave), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // free for the next launch
-}
-
 // ================================================================================================
 // 256 x 256 tile.  waves 2 (M) x 4 (N); wave (wm, wn) owns rows {a*128 + wm*64 + mi*32 + [0,32)} and columns
 // {b*128 + wn*32 + [0,32)} for a, mi, b in {0,1}: each 128-row half of the A tile and each 128-row half of the W tile is
@@ -259,12 +180,9 @@ __device__ __forceinline__ void pp_walk_epilogue(const CtkGemmP& g, const PPWalk
 // every wave has waited for its pieces of blocks <= g + 2 at the end of the load segment of phase g (vmcnt(8): the 4
 // younger blocks stay in flight), one s_barrier before any wave reads them.
 // LDS: A blocks at (J&1)*32K + a*16K, B blocks at 64K + (J&1)*32K + b*16K.
-// DIM (round 5 experiment, ctk_gemm_pp_mode bit 7): the phase's LDS-DMA pieces are issued INSIDE its MFMA burst (behind the second
-// MFMA) instead of in the load segment in front of the barrier.  The wave timeline (profiles/r05_gemm_wave_timeline_before.txt)
-// shows a phase period of ~1150-1400 cycles against 2 x 384 of MFMA issue: the load segment (fragment reads + 2-3 DMA pieces at
-// 100-185 cycles each + their address arithmetic), not the matrix pipe, paces a phase.  A piece costs ~60 cycles among MFMAs.
-// The waits sit where they were; a phase's own pieces are now issued BEHIND its wait, so every count drops by that block.
-template <int EPI, bool DBG, int TAG = 0, int DIM = 0>  // TAG: no code difference, only a distinct kernel NAME per Linear for rocprofv3 (tools/pmc_traffic.py)
+// (Round 5 measured the phase's LDS-DMA pieces issued INSIDE its MFMA burst instead of in the load segment: +-0, bit-identical --
+// profiles/r05_dma_in_mfma_ab.txt; the variant left the tree in round 6.)
+template <int EPI, bool DBG, int TAG = 0>  // TAG: no code difference, only a distinct kernel NAME per Linear for rocprofv3 (tools/pmc_traffic.py)
 __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
   const int dbg = DBG ? dbg_arg : 0;  // the experiment knobs exist only in the DBG instantiations
   constexpr int BM = 256, BN = 256;
@@ -281,7 +199,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   const int wm = wave >> 2, wn = wave & 3;
   const int r32 = lane & 31, half = lane >> 5;
 
-  const PPWalk walk = pp_walk_init(g, tiles_total, KT, pp_sk_epi(EPI));
+  const PPWalk walk = pp_walk_init(tiles_total, KT);
   PPTile tile;
   if (!pp_tile<BM, BN>(g, walk, 0, tile)) return;
   const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
@@ -358,29 +276,21 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
   auto scratch = [&]() { return grp == 0 ? lds + RING + PP_BIAS_BYTES + wave * 4096 : lds + (par ^ 1) * 32768 + 16384 + (wave & 3) * 4096; };
   PPResid<4, 2> resid;
   auto resid_issue = [&]() { pp_resid_issue<EPI, 4, 2>(g, resid, lane, tile.bz, row_of, col_of); };
-  // (a workgroup that starts in the middle of a tile contributes K-tiles only: its accumulators start from 0 x residual)
   auto init_acc = [&](const float sc) { pp_init_acc<EPI, 4, 2>(acc, resid, lane, sc, scratch()); };
   // operands swapped on purpose (D'[n][m]: lane = output row, register quad = 4 consecutive columns); small terms first
-  auto mma_dma = [&](const int a, const int b, auto issue) {  // `issue` runs behind the second MFMA (DIM) or not at all
+  auto mma = [&](const int a, const int b) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int term = 0; term < 3; ++term) {
+      for (int term = 0; term < 3; ++term)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[a * 2 + mi][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[b][j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0],
                                                                       acc[a * 2 + mi][b], 0, 0, 0);
-        if (DIM && j == 0 && term == 0) {
-          PP_SCHED_FENCE();
-          issue();
-          PP_SCHED_FENCE();
-        }
-      }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto mma = [&](const int a, const int b) { mma_dma(a, b, [] {}); };
-  constexpr int WV = DIM ? 6 : 8;  // in flight behind a phase's wait: 3 blocks (DIM: its own block is not issued yet) or 4
+  constexpr int WV = 8;  // in flight behind a phase's wait: 4 blocks
 
   // ---- stream set-up: blocks 0..5 = K-tile 0 (all four) + K-tile 1 (A_0, B_0)
   PPCursor c1, c2;  // K-tiles J+1 and J+2 of the stream
@@ -398,7 +308,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
     pp_cursor_next<BM, BN>(g, walk, c2);
   }
   resid_issue();
-  init_acc(tile.kb > 0 ? 0.0f : w_scale);
+  init_acc(w_scale);
   PP_WAIT_VM(8);   // blocks 0, 1 (K-tile 0: A_0, B_0) have landed
   PP_BARRIER();
   if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one barrier behind group 0
@@ -408,38 +318,38 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
       // ---- phase 0 (a=0, b=0): read A_0, B_0; issue B_1 of K-tile J+1
       read_a(0);
       read_b(0);
-      if (!DIM) dma_b(c1, 1, par ^ 1);
+      dma_b(c1, 1, par ^ 1);
       PP_WAIT_VM(WV);
       PP_BARRIER();
       PP_WAIT_LGKM0();
       PP_STAMP();
-      mma_dma(0, 0, [&] { dma_b(c1, 1, par ^ 1); });
+      mma(0, 0);
       PP_BARRIER();
       // ---- phase 1 (a=0, b=1): read B_1; issue A_1 of K-tile J+1
       read_b(1);
-      if (!DIM) dma_a(c1, 1, par ^ 1);
+      dma_a(c1, 1, par ^ 1);
       PP_WAIT_VM(WV);
       PP_BARRIER();
       PP_WAIT_LGKM0();
       PP_STAMP();
-      mma_dma(0, 1, [&] { dma_a(c1, 1, par ^ 1); });
+      mma(0, 1);
       PP_BARRIER();
       // ---- phase 2 (a=1, b=1): read A_1; issue A_0 of K-tile J+2 (into the slot A_0 of this K-tile left in phase 0)
       read_a(1);
-      if (!DIM) dma_a(c2, 0, par);
+      dma_a(c2, 0, par);
       PP_WAIT_VM(WV);
       PP_BARRIER();
       PP_WAIT_LGKM0();
       PP_STAMP();
-      mma_dma(1, 1, [&] { dma_a(c2, 0, par); });
+      mma(1, 1);
       PP_BARRIER();
       // ---- phase 3 (a=1, b=0): nothing to read (B_0 is still in registers); issue B_0 of K-tile J+2
-      if (!DIM) dma_b(c2, 0, par);
+      dma_b(c2, 0, par);
       PP_WAIT_VM(WV);
       const bool last = kt + 1 == tile.ke;
       PP_BARRIER();
       PP_STAMP();
-      mma_dma(1, 0, [&] { dma_b(c2, 0, par); });
+      mma(1, 0);
       if (!last) PP_BARRIER();
       // advance the stream
       c1 = c2;
@@ -462,9 +372,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
     const PPTile done = tile;
     const bool more = pp_tile<BM, BN>(g, walk, q + 1, tile);
     resid_issue();  // unconditional (on the last tile it re-reads valid addresses; a conditional re-init doubles the live accumulators)
-    pp_walk_epilogue<EPI, BM, BN, 4, 2>(g, walk, done, acc, lane, wave, w_unscale, bias_lds, scratch(),
-                                        [&](int i) { return done.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; }, [&](int b) { return done.n0 + wn * 32 + b * 128; },
-                                        (dbg & 2) != 0);
+    pp_epilogue<EPI, 4, 2>(g, acc, lane, done.bz, w_unscale, bias_lds, scratch(),
+                           [&](int i) { return done.m0 + wm * 64 + (i >> 1) * 128 + (i & 1) * 32; }, [&](int b) { return done.n0 + wn * 32 + b * 128; },
+                           (dbg & 2) != 0);
     init_acc(w_scale);
     PP_STAMP();  // epilogue done
     if (grp == 1) PP_BARRIER();
@@ -485,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(CtkGemmP g, int tiles_t
 // block i = 3 J + k is issued in phase i - 4 into the K-tile slot (J & 1) (56 KiB each), where block i - 6 was last read
 // >= 2 phases earlier; waits: end of phase 3J+2 -> I0, I1 of K-tile J+1 (vmcnt(5): I2(J+1) and I0(J+2) stay in flight),
 // end of phase 3J -> I2 of K-tile J (vmcnt(5)), end of phase 3J+1 -> nothing new.
-template <int EPI, bool DBG, int TAG = 0, int DIM = 0>  // DIM: see gemm_pp256_kernel
+template <int EPI, bool DBG, int TAG = 0>
 __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_total, int dbg_arg) {
   const int dbg = DBG ? dbg_arg : 0;
   constexpr int BM = 256, BN = 192;
@@ -502,7 +412,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, half = lane >> 5;
 
-  const PPWalk walk = pp_walk_init(g, tiles_total, KT, pp_sk_epi(EPI));
+  const PPWalk walk = pp_walk_init(tiles_total, KT);
   PPTile tile;
   if (!pp_tile<BM, BN>(g, walk, 0, tile)) return;
   const float* bias_lds = reinterpret_cast<const float*>(lds + RING);
@@ -641,22 +551,16 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
   };
-  auto mma_dma = [&](const int n, auto issue) {  // `issue` runs behind the second MFMA (DIM) or not at all
+  auto mma = [&](const int n) {
     if (no_mfma) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int term = 0; term < 3; ++term) {
+      for (int term = 0; term < 3; ++term)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][term == 0 ? 1 : 0], fa[mi][j][term == 1 ? 1 : 0], acc[mi][n], 0, 0, 0);
-        if (DIM && j == 0 && term == 0) {
-          PP_SCHED_FENCE();
-          issue();
-          PP_SCHED_FENCE();
-        }
-      }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -692,36 +596,36 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     read_a();
     read_b(0);
     if constexpr (RD0) res_read();
-    if (!DIM) issue_i1(c1, par ^ 1);
-    PP_WAIT_VM(DIM ? 3 : 5);  // (DIM: behind I2 of this K-tile only I0 of the next one is in flight; I1 follows inside the MFMAs)
+    issue_i1(c1, par ^ 1);
+    PP_WAIT_VM(5);
     PP_BARRIER();
     PP_WAIT_LGKM0();
     PP_STAMP();
-    mma_dma(0, [&] { issue_i1(c1, par ^ 1); });
+    mma(0);
     if constexpr (RD0) res_add(std::integral_constant<int, (RD0 ? I - 2 : 0)>{});
     PP_BARRIER();
     // ---- phase 1: read B_1; issue I2 of K-tile J+1
     read_b(1);
-    if (!DIM) issue_i2(c1, par ^ 1);
+    issue_i2(c1, par ^ 1);
     if constexpr (WR) res_write();
     if constexpr (LD) res_load(std::integral_constant<int, (LD ? I : 0)>{});
     PP_BARRIER();
     PP_WAIT_LGKM0();
     PP_STAMP();
-    mma_dma(1, [&] { issue_i2(c1, par ^ 1); });
+    mma(1);
     PP_BARRIER();
     // ---- phase 2: read B_2; issue I0 of K-tile J+2 (the A rows of this K-tile were read in phase 0); wait for I0, I1 of J+1
     read_b(2);
     if constexpr (RD2) res_read();
-    if (!DIM) issue_i0(c2, par);
-    // behind I0 / I1 of K-tile J+1: I2 of J+1 (2 pieces) and, where this K-tile carries them, the 4 residual pieces of phase 1 --
-    // in front of I2 when it is issued inside the MFMAs (DIM), behind it otherwise -- and (not DIM) I0 of K-tile J+2
-    PP_WAIT_VM((DIM ? 2 : 5) + (LD ? 4 : 0));
+    issue_i0(c2, par);
+    // behind I0 / I1 of K-tile J+1: I2 of J+1 (2 pieces), where this K-tile carries them the 4 residual pieces of phase 1 (issued
+    // behind I2), and I0 of K-tile J+2
+    PP_WAIT_VM(5 + (LD ? 4 : 0));
     const bool last = kt + 1 == tile.ke;
     PP_BARRIER();
     PP_WAIT_LGKM0();
     PP_STAMP();
-    mma_dma(2, [&] { issue_i0(c2, par); });
+    mma(2);
     if constexpr (RD2) res_add(std::integral_constant<int, (RD2 ? I - 1 : 0)>{});
     if (!last) PP_BARRIER();
     c1 = c2;
@@ -733,7 +637,7 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   };
   for (int q = 0;; ++q) {
     kt = tile.kb;
-    if constexpr (RP) {  // (a "+ residual" tile has >= 8 K-tiles and starts at K-tile 0: ctk_launch_gemm_pp; pp_sk_epi)
+    if constexpr (RP) {  // (a "+ residual" tile has >= 8 K-tiles: ctk_launch_gemm_pp)
       ktile(std::integral_constant<int, 0>{});
       ktile(std::integral_constant<int, 1>{});
       ktile(std::integral_constant<int, 2>{});
@@ -748,8 +652,8 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
     PP_STAMP();  // epilogue begins
     const PPTile done = tile;
     const bool more = pp_tile<BM, BN>(g, walk, q + 1, tile);
-    pp_walk_epilogue<EPI, BM, BN, 2, 3>(g, walk, done, acc, lane, wave, w_unscale, bias_lds, scr,
-                                        [&](int mi) { return done.m0 + wm * 64 + mi * 32; }, [&](int ni) { return done.n0 + wn * 32 + ni * 64; }, (dbg & 2) != 0);
+    pp_epilogue<EPI, 2, 3>(g, acc, lane, done.bz, w_unscale, bias_lds, scr,
+                           [&](int mi) { return done.m0 + wm * 64 + mi * 32; }, [&](int ni) { return done.n0 + wn * 32 + ni * 64; }, (dbg & 2) != 0);
     init_acc();
     PP_STAMP();  // epilogue done
     if (grp == 1) PP_BARRIER();
@@ -761,8 +665,6 @@ __global__ __launch_bounds__(512) void gemm_pp192_kernel(CtkGemmP g, int tiles_t
   pp_clock_probe(1, tid);
 }
 
-thread_local int t_pp_cu_limit = 0;
-
 int pp_num_cus() {
   static const int n = [] {
     int dev = 0, cu = 0;
@@ -772,42 +674,15 @@ int pp_num_cus() {
   return n;
 }
 
-int g_pp_mode = [] { const char* e = getenv("CTK_GEMM_PP"); return e ? atoi(e) : 33; }();  // (env: initial value, read once) bit 0: 0 = off (gemm_f16x3.hip's kernels), 1 = auto; bit 5 (32): tail split (see ctk_launch_gemm_pp); bit 4 (16): stream-K walk where a scratch buffer was lent (OFF by default, see the tile walk); experiments: bit 1 = no stores, bit 3 = timing jitter, bits 8.. = start stagger
-
-thread_local void* t_sk_mem = nullptr;
-thread_local size_t t_sk_bytes = 0;
-thread_local hipStream_t t_sk_stream = nullptr;
-
 }  // namespace
 
-CtkPPCuLimit::CtkPPCuLimit(int n) : prev_(t_pp_cu_limit) { t_pp_cu_limit = n; }
-CtkPPCuLimit::~CtkPPCuLimit() { t_pp_cu_limit = prev_; }
+// include/ctk.h: the historical name of ctk_set_option(CTK_OPT_GEMM_PP, mode)
+extern "C" void ctk_gemm_pp_mode(int mode) { ctk_set_option(CTK_OPT_GEMM_PP, mode); }
 
-size_t ctk_pp_scratch_bytes() { return (size_t)PP_SK_FLAG_BYTES + (size_t)pp_num_cus() * PP_SK_SLOT_MAX; }
-// what a window / update-former workspace reserves for it: nothing unless the opt-in stream-K walk (mode bit 4) is on at
-// workspace-size query time (it was ~64 MiB per workspace and per captured graph for a default-off experiment)
-size_t ctk_pp_scratch_bytes_if_enabled() { return (g_pp_mode & 16) ? ctk_pp_scratch_bytes() : 0; }
-
-CtkPPScratchScope::CtkPPScratchScope(void* mem, size_t bytes, hipStream_t s) : prev_mem_(t_sk_mem), prev_bytes_(t_sk_bytes), prev_stream_(t_sk_stream) {
-  if (mem && bytes >= ctk_pp_scratch_bytes() && (g_pp_mode & 16) != 0 && hipMemsetAsync(mem, 0, PP_SK_FLAG_BYTES, s) == hipSuccess) {
-    t_sk_mem = mem;
-    t_sk_bytes = bytes;
-    t_sk_stream = s;
-  } else {
-    t_sk_mem = nullptr;
-  }
-}
-CtkPPScratchScope::~CtkPPScratchScope() {
-  t_sk_mem = prev_mem_;
-  t_sk_bytes = prev_bytes_;
-  t_sk_stream = prev_stream_;
-}
-
-extern "C" void ctk_gemm_pp_mode(int mode) { g_pp_mode = mode; }
-
-// dev tool (tools/gemm_lab trace; not part of include/ctk.h): the wave timeline the last DBG launch with mode bit 6 recorded,
-// [PP_TRACE_WGS workgroups][8 waves][PP_TRACE_STAMPS] s_memtime values (0 = not written)
-// dev tool: {s_memtime, s_memrealtime (100 MHz)} at the start and at the end of workgroup 0 of the LAST persistent GEMM launch
+#ifdef CTK_DEV
+// dev tools (make dev; tools/gemm_lab trace / clock; not part of include/ctk.h).
+// ctk_debug_pp_clock: {s_memtime, s_memrealtime (100 MHz)} at the start and at the end of workgroup 0 of the LAST persistent launch;
+// ctk_debug_pp_trace: the wave timeline the last DBG launch with mode bit 6 recorded, [PP_TRACE_WGS][8 waves][PP_TRACE_STAMPS].
 extern "C" int ctk_debug_pp_clock(unsigned long long* host_out4) {
   if (!host_out4) return CTK_E_NULL;
   const hipError_t e = hipMemcpyFromSymbol(host_out4, HIP_SYMBOL(g_pp_clock), 32);
@@ -819,29 +694,7 @@ extern "C" int ctk_debug_pp_trace(unsigned long long* host_out, int n) {
   const hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_trace), (size_t)n * 8);
   return e == hipSuccess ? CTK_OK : (int)e;
 }
-
-extern "C" int ctk_gemm_scratch_bytes(size_t* out_bytes) {
-  if (!out_bytes) return CTK_E_NULL;
-  *out_bytes = ctk_pp_scratch_bytes();
-  return CTK_OK;
-}
-
-// Lend (or, with mem == null, take back) a stream-K scratch buffer to the ctk_gemm calls this thread issues on `stream`.
-extern "C" int ctk_gemm_set_scratch(void* mem, size_t bytes, void* stream) {
-  t_sk_mem = nullptr;
-  t_sk_bytes = 0;
-  t_sk_stream = nullptr;
-  if (!mem) return CTK_OK;
-  if (!ctk_aligned16(mem)) return CTK_E_ALIGN;
-  if (bytes < ctk_pp_scratch_bytes()) return CTK_E_WORKSPACE;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const hipError_t e = hipMemsetAsync(mem, 0, PP_SK_FLAG_BYTES, s);
-  if (e != hipSuccess) return (int)e;
-  t_sk_mem = mem;
-  t_sk_bytes = bytes;
-  t_sk_stream = s;
-  return CTK_OK;
-}
+#endif
 
 // the compile-time epilogues the persistent kernels are instantiated for (the PP_CASE list below)
 static bool pp_epi_supported(int code) {
@@ -850,20 +703,19 @@ static bool pp_epi_supported(int code) {
          code == pp_epi(CTK_ACT_NONE, true, false, false, true) || code == pp_epi(CTK_ACT_GELU_TANH, false, true, false, true);
 }
 
-// Tail split (g_pp_mode bit 5, default ON).  A persistent launch deals whole 256-row tiles in rounds of #CUs: the N = 384
+// Tail split (CTK_OPT_GEMM_PP bit 5, default ON).  A persistent launch deals whole 256-row tiles in rounds of #CUs: the N = 384
 // Linears of a C3 window are 800 / 808 tiles = 3 full rounds + a round that is 1/8 full, and the launch lasts four tile times
 // (profiles/r03_gemm_lab_streamk.txt: mlp.fc2 350 us for 768 tiles, 414 us for 800).  When the last round would be at most
-// CTK_GEMM_TAIL_PCT % full (default 25), the persistent kernel gets the whole rounds only and the remaining row blocks go to the
+// CTK_OPT_GEMM_TAIL_PCT % full (default 25), the persistent kernel gets the whole rounds only and the remaining row blocks go to the
 // 64 x 64-tile kernel of gemm_f16x3.hip (same split-half arithmetic, same K order inside a row), which spreads them over
-// every CU.  Rows are independent, so the result does not depend on where the cut is.
-static int pp_tail_pct() {
-  static const int pct = [] { const char* e = getenv("CTK_GEMM_TAIL_PCT"); return e ? atoi(e) : 25; }();
-  return pct;
-}
-
+// every CU.  Rows are independent, so the result does not depend on where the cut is -- up to ONE rounding for the "+ residual"
+// Linears (to_out, mlp.fc2): the persistent kernel adds residual * s into the accumulators during its first K-tiles, the 64 x 64
+// kernel adds the residual after unscale and bias (tests/test_gpu_gemm_pp.py bounds the difference by 4e-6 relative).
+//
 // Returns CTK_OK after launching, or -1 when the shape is not one of the persistent kernels' (caller falls back).
 int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
-  if ((g_pp_mode & 1) == 0 || !g.a_split || !g.Wp) return -1;
+  const int mode = ctk_opt(CTK_OPT_GEMM_PP);
+  if ((mode & 1) == 0 || !g.a_split || !g.Wp) return -1;
   const bool t256 = (g.N % 256) == 0, t192 = !t256 && (g.N % 192) == 0;
   if ((!t256 && !t192) || g.N * 4 > PP_BIAS_BYTES) return -1;
   if (g.lda * 2 > 0xffffff) return -1;  // row offsets are formed with 32-bit arithmetic inside a tile
@@ -873,7 +725,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   long tiles = (long)mblocks * nblocks * g.batch;
   const int cus = pp_num_cus();
   if (tiles < cus) return -1;  // less than one tile per CU (virtual-track GEMMs, short streaming windows): the 64x64 / 128x128 kernels fill the chip better (tools/gemm_lab.cpp)
-  const int wgs = (t_pp_cu_limit > 0 && t_pp_cu_limit < cus) ? t_pp_cu_limit : cus;  // (CtkPPCuLimit: leave CUs to concurrent small launches)
+  const int wgs = cus;
   const int code = pp_epi(g.act, g.resid != nullptr, g.c_split != 0, g.bias_rows != nullptr, g.bias != nullptr);
   if (g.resid && g.K < 8 * 32) return -1;  // the residual rides on a tile's first eight K-tiles (gemm_pp192_kernel)
   if (t256 && g.resid) return -1;  // residual preload of a 128-register accumulator tile spills; no Linear of the path has this shape
@@ -882,7 +734,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   CtkGemmP tail = g;
   int tail_rows = 0;
   const long rem = tiles % wgs;
-  if ((g_pp_mode & 32) != 0 && g.batch == 1 && tiles > wgs && rem > 0 && rem * 100 <= (long)wgs * pp_tail_pct()) {
+  if ((mode & 32) != 0 && g.batch == 1 && tiles > wgs && rem > 0 && rem * 100 <= (long)wgs * ctk_opt(CTK_OPT_GEMM_TAIL_PCT)) {
     const int mb_full = (int)((tiles - rem) / nblocks);  // row blocks of the whole rounds (rounded down to whole row blocks)
     const long rows_full = (long)mb_full * 256;
     if (mb_full > 0 && (!g.bias_rows || rows_full % g.bias_period == 0)) {
@@ -906,20 +758,18 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
   char pname[40];
   snprintf(pname, sizeof(pname), "gemm_sh_pp%d_k%d_n%d", BN, g.K, g.N);
   CtkProfScope ps(pname, flops * frac, bytes * frac, s);
-  // stream-K only on the stream whose entry point lent the scratch (one persistent GEMM at a time uses the slots)
-  g.sk = (t_sk_mem && s == t_sk_stream && (g_pp_mode & 16) != 0 && wgs == cus && cus <= PP_SK_FLAG_BYTES / 32 && tiles % cus != 0 && pp_sk_epi(code)) ? t_sk_mem : nullptr;  // (never under a CU limit: the slots are per CU of a full-width launch)
-  const bool dbgk = (g_pp_mode & ~(17 | 32 | 128)) != 0;  // (bit 6 = wave timeline: DBG kernels)
-  const bool dim = (g_pp_mode & 128) != 0;  // DMA pieces inside the MFMA bursts
+#ifdef CTK_DEV
+  const bool dbgk = (mode & ~(1 | 32)) != 0;  // experiments (DBG instantiations): bit 1 = no stores, 2 = no MFMAs, 3 = timing jitter, 6 = wave timeline, 8.. = start stagger
+#define PP_DBG_CASE(K, E) if (dbgk) hipLaunchKernelGGL((K<E, true>), grid, blk, 0, s, g, (int)tiles, mode); else
+#else
+#define PP_DBG_CASE(K, E)
+#endif
 #define PP_CASE(E)                                                                                             \
   case E:                                                                                                      \
-    if (t256 && dbgk) hipLaunchKernelGGL((gemm_pp256_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);   \
-    else if (t256 && dim) hipLaunchKernelGGL((gemm_pp256_kernel<E, false, 0, 1>), grid, blk, 0, s, g, (int)tiles, 0); \
-    else if (t256) hipLaunchKernelGGL((gemm_pp256_kernel<E, false>), grid, blk, 0, s, g, (int)tiles, 0);       \
-    else if (dbgk) hipLaunchKernelGGL((gemm_pp192_kernel<E, true>), grid, blk, 0, s, g, (int)tiles, g_pp_mode);      \
-    else if (dim && g.K > 768) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 1, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
-    else if (dim) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 0, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
-    else if (g.K > 768) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
-    else hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 0>), grid, blk, 0, s, g, (int)tiles, 0);              \
+    if (t256) { PP_DBG_CASE(gemm_pp256_kernel, E) hipLaunchKernelGGL((gemm_pp256_kernel<E, false>), grid, blk, 0, s, g, (int)tiles, 0); } \
+    else { PP_DBG_CASE(gemm_pp192_kernel, E) {                                                                  \
+      if (g.K > 768) hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 1>), grid, blk, 0, s, g, (int)tiles, 0);  \
+      else hipLaunchKernelGGL((gemm_pp192_kernel<E, false, 0>), grid, blk, 0, s, g, (int)tiles, 0); } }        \
     break
   switch (code) {
     PP_CASE(pp_epi(CTK_ACT_GELU_ERF, false, true, false, true));    // corr_mlp.fc1
@@ -932,6 +782,7 @@ int ctk_launch_gemm_pp(CtkGemmP& g, double flops, double bytes, hipStream_t s) {
       return -1;
   }
 #undef PP_CASE
+#undef PP_DBG_CASE
   CTK_HIP_CHECK_LAUNCH();
   }
   if (tail_rows) return ctk_launch_gemm_sh64(tail, flops * (1.0 - frac), bytes * (1.0 - frac), s);

@@ -75,30 +75,16 @@ constexpr int pp_epi(int act, bool res, bool split, bool brows, bool bias) {
 // position c ^ (r & 7): conflict-free writes) and leaves as 4 dwordx4 stores of 8 full 128-byte lines each.
 // The bias vector lives in LDS too (bias_lds, staged once per workgroup): an ordinary global load in the epilogue would
 // make hipcc drain the whole LDS-DMA queue (vmcnt(0)) at its first use AND at the top of the next tile.  The residual
-// (EPI bit 2) is not added here: pp_init_acc preloads it, scaled, into the accumulators at the start of the tile.
-// Where a tile's epilogue writes and what it adds on the way out.  Normally the output matrix; the stream-K walk of
-// gemm_pp.hip routes the first (partial) tile of a workgroup into a scratch tile instead and lets the workgroup that owns
-// the rest of that tile ADD the scratch tile to its own result -- on the read-back side of the LDS transpose, where both
-// are runs of whole 128-byte lines (only for f32 outputs without activation: the epilogue is linear there).
-struct PPEpiIO {
-  unsigned char* c;          // row 0, column 0 of the destination (batch offset included), bytes
-  long ldc;                  // destination row pitch in elements (floats, or halves / 2 for SH)
-  int M;                     // rows >= M are not stored
-  const unsigned char* add;  // null, or row 0 / column 0 of an f32 matrix (pitch add_ld floats) added to the result
-  long add_ld;
-  float bias_scale;          // 1, or 0 for a partial tile (bias * 1 is exact; a second bias POINTER would cost address registers)
-  int through;               // the destination is read by another workgroup of this launch: stores go THROUGH the caches (sc0 sc1)
-};
-
+// (EPI bit 2) is not added here: it is in the accumulators already (256 x 192: rides on the tile's first K-tiles).
 template <int EPI, int MI, int NI, class RowOf, class ColOf>
-__device__ __forceinline__ void pp_epilogue_io(const CtkGemmP& g, const PPEpiIO& io, f32x16 (&acc)[MI][NI], const int lane, const float unscale,
-                                               const float* bias_lds, unsigned char* scratch /* 4 KiB, this wave's */, RowOf row_of,
-                                               ColOf col_of, const bool no_store = false, const int n_valid = 0x7fffffff) {
+__device__ __forceinline__ void pp_epilogue(const CtkGemmP& g, f32x16 (&acc)[MI][NI], const int lane, const int bz, const float unscale,
+                                            const float* bias_lds, unsigned char* scratch /* 4 KiB, this wave's */, RowOf row_of,
+                                            ColOf col_of, const bool no_store = false, const int n_valid = 0x7fffffff) {
   constexpr int ACT = EPI & 3;
   constexpr bool SPLIT = (EPI & 8) != 0, BROWS = (EPI & 16) != 0, BIAS = (EPI & 32) != 0;
-  constexpr bool ADD = ACT == 0 && !SPLIT && !BROWS;  // the instantiations that can take part in stream-K
+  unsigned char* const c0 = static_cast<unsigned char*>(g.C) + (long)bz * g.c_bs * (SPLIT ? 2 : 4);  // row 0, column 0 of the destination
   const int r32 = lane & 31, half = lane >> 5;
-  constexpr bool BV_REGS = (EPI & 4) == 0;  // residual kernels hold the next tile's residual in registers here: bias straight from LDS
+  constexpr bool BV_REGS = (EPI & 4) == 0;  // residual kernels are short of registers here: bias straight from LDS
   f32x4 bv[NI][4];
   if (BIAS && BV_REGS) {
 #pragma unroll
@@ -110,51 +96,28 @@ __device__ __forceinline__ void pp_epilogue_io(const CtkGemmP& g, const PPEpiIO&
   const int wsw = r32 & 7;
   const int rrow = lane >> 3, rchunk = lane & 7;  // read-back: 8 lanes per row, 8 rows per instruction
   const unsigned char* rd = scratch + rrow * 128 + ((rchunk ^ rrow) << 4);
-  const bool full = row_of(MI - 1) + 32 <= io.M;   // wave-uniform: no row of this wave's tile is beyond M
-  const long row_step = (long)8 * io.ldc * (SPLIT ? 2 : 4);
-  const bool adding = ADD && io.add != nullptr;    // wave-uniform
+  const bool full = row_of(MI - 1) + 32 <= g.M;   // wave-uniform: no row of this wave's tile is beyond M
+  const long row_step = (long)8 * g.ldc * (SPLIT ? 2 : 4);
   // software pipeline over the MI x NI sub-tiles: the 4 read-backs of sub-tile k are issued right behind its writes (the LDS
   // serves a wave's accesses in order) and stored one sub-tile later, behind the next sub-tile's arithmetic
   f32x4 pend[4];
   unsigned char* pend_dst = nullptr;
-  int pend_col = 0;  // (wave-uniform)
   int pend_row0 = 0;
-  // The two workgroups that exchange a partial tile may sit on different XCDs, i.e. behind different L2s.  An agent-scope
-  // release / acquire pair is correct but writes back / invalidates a whole L2 each time (measured: +180 us per launch with
-  // 224 producers); instead the partial tile itself bypasses the caches -- system-scope stores on the way out, system-scope
-  // loads on the way in -- and the flags only have to be ordered behind an s_waitcnt vmcnt(0).
   auto flush = [&]() {
-    if (adding) {  // (loaded here, not a sub-tile ahead: one tile per launch and workgroup takes this path, registers are scarcer than its latency)
-      f32x4 t[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned char* src = io.add + ((long)(pend_row0 + 8 * i) * io.add_ld + pend_col) * 4 + rchunk * 16;
-        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(t[i]) : "v"(src) : "memory");
-      }
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : : "memory");
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pend[i] += t[i];
-    }
-    if (ADD && io.through) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        unsigned char* dst = pend_dst + i * row_step;
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(pend[i]) : "memory");
-      }
-    } else if (full) {
+    if (full) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(pend_dst + i * row_step) = pend[i];
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (pend_row0 + 8 * i < io.M) *reinterpret_cast<f32x4*>(pend_dst + i * row_step) = pend[i];
+        if (pend_row0 + 8 * i < g.M) *reinterpret_cast<f32x4*>(pend_dst + i * row_step) = pend[i];
     }
   };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int rowc = min(row_of(mi) + r32, g.M - 1);
     const float* bp = BROWS ? g.bias_rows + (long)(rowc % g.bias_period) * g.N + half * 4 : nullptr;
-    unsigned char* crow = io.c + (long)(row_of(mi) + rrow) * io.ldc * (SPLIT ? 2 : 4) + rchunk * 16;
+    unsigned char* crow = c0 + (long)(row_of(mi) + rrow) * g.ldc * (SPLIT ? 2 : 4) + rchunk * 16;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       if (col_of(ni) >= n_valid) continue;  // zero-padded output columns (the encoder's 64 / 96-channel convolutions on 128-column tiles)
@@ -163,15 +126,7 @@ __device__ __forceinline__ void pp_epilogue_io(const CtkGemmP& g, const PPEpiIO&
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][q * 4 + e] * unscale;
-        if (BIAS) {
-          const f32x4 bq = BV_REGS ? bv[ni][q] : *reinterpret_cast<const f32x4*>(bias_lds + col_of(ni) + q * 8 + half * 4);
-          if (ADD) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(bq[e], io.bias_scale, v[e]);
-          } else {
-            v += bq;
-          }
-        }
+        if (BIAS) v += BV_REGS ? bv[ni][q] : *reinterpret_cast<const f32x4*>(bias_lds + col_of(ni) + q * 8 + half * 4);
         if (BROWS) v += *reinterpret_cast<const f32x4*>(bp + col_of(ni) + q * 8);
         if (ACT == CTK_ACT_GELU_ERF) {
 #pragma unroll
@@ -192,21 +147,12 @@ __device__ __forceinline__ void pp_epilogue_io(const CtkGemmP& g, const PPEpiIO&
       if (pend_dst != nullptr && !no_store) flush();
 #pragma unroll
       for (int i = 0; i < 4; ++i) pend[i] = *reinterpret_cast<const f32x4*>(rd + i * 1024);
-      pend_col = col_of(ni);
       // column offset of this sub-tile inside the output row: SH = (col/32) lines of 128 B, f32 = col * 4 B -- the same number
       pend_dst = crow + (long)col_of(ni) * 4;
       pend_row0 = row_of(mi) + rrow;
     }
   }
   if (pend_dst != nullptr && !no_store) flush();
-}
-
-template <int EPI, int MI, int NI, class RowOf, class ColOf>
-__device__ __forceinline__ void pp_epilogue(const CtkGemmP& g, f32x16 (&acc)[MI][NI], const int lane, const int bz, const float unscale,
-                                            const float* bias_lds, unsigned char* scratch /* 4 KiB, this wave's */, RowOf row_of,
-                                            ColOf col_of, const bool no_store = false, const int n_valid = 0x7fffffff) {
-  const PPEpiIO io{static_cast<unsigned char*>(g.C) + (long)bz * g.c_bs * ((EPI & 8) ? 2 : 4), g.ldc, g.M, nullptr, 0, 1.0f, 0};
-  pp_epilogue_io<EPI, MI, NI>(g, io, acc, lane, unscale, bias_lds, scratch, row_of, col_of, no_store, n_valid);
 }
 
 template <int EPI>

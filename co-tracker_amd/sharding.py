@@ -26,36 +26,14 @@ def shard_queries(queries: torch.Tensor, world: int, rank: int) -> torch.Tensor:
     return queries[:, lo:hi]
 
 
-# Whether the process group's backend has the flat all-gather, decided ONCE per (backend, device type) on a 1-element tensor.
-# Every rank takes the probe at the same point of the same call, so it is itself a matched collective; what it catches is
-# "this backend does not implement the operator", and only that -- an error of a REAL collective (RCCL failure, timeout,
-# shape mismatch between ranks) propagates to the caller instead of being answered with a second, different collective that
-# the other ranks may never join (review of round 4).
-_FLAT_OK = {}
-
-
+# Which collective carries the gather is decided WITHOUT communicating (review of round 5: a probe collective cached per process,
+# not per group, can leave ranks with different cache states issuing different collectives): the "nccl" backend (= RCCL on ROCm)
+# has ncclAllGather behind all_gather_into_tensor; every other backend (gloo in the CPU / single-device tests) takes
+# dist.all_gather on per-rank VIEWS of the same preallocated buffer -- the same bytes in the same place, still no list of fresh
+# tensors and no torch.cat.  The choice is a pure function of the group's backend name, identical on every rank of the group, and
+# an error of the collective itself (RCCL failure, timeout, shape mismatch between ranks) propagates to the caller.
 def _flat_all_gather_ok(device: torch.device, group=None) -> bool:
-    backend = str(dist.get_backend(group))
-    key = (backend, device.type)
-    if key not in _FLAT_OK:
-        if backend == "nccl":  # ncclAllGather (RCCL): always there
-            _FLAT_OK[key] = True
-        else:
-            world = dist.get_world_size(group)
-            probe_in = torch.zeros(1, device=device)
-            probe_out = torch.zeros(world, device=device)
-            try:
-                dist.all_gather_into_tensor(probe_out, probe_in, group=group)
-                _FLAT_OK[key] = True
-            except NotImplementedError:
-                _FLAT_OK[key] = False
-            except RuntimeError as e:  # torch's "backend does not support ..." is a RuntimeError; anything else is a real failure
-                msg = str(e).lower()
-                if "not support" in msg or "not implemented" in msg or "unsupported" in msg:
-                    _FLAT_OK[key] = False
-                else:
-                    raise
-    return _FLAT_OK[key]
+    return str(dist.get_backend(group)) == "nccl" and device.type == "cuda"
 
 
 def _gather_flat(full: torch.Tensor, mine: torch.Tensor, world: int, group=None) -> None:

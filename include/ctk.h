@@ -10,7 +10,12 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer is DEVICE memory (float32 unless
  *    stated) owned by the caller; the library never allocates, frees or retains
- *    device memory and keeps no mutable global state (re-entrant).
+ *    device memory.  Its only process-wide state is (i) the option table of
+ *    ctk_set_option (validated relaxed atomics: a launch uses what it reads when it is
+ *    enqueued; no option changes what is computed), (ii) the opt-in bench recorder
+ *    (ctk_profile_enable) and (iii) per-device caches of read-only queries (CU count,
+ *    fork/join event rings); kernels write no device-side globals.  Entry points may be
+ *    called concurrently from several host threads on different streams.
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no host
  *    synchronisation, no host reads of device data -> safe under stream capture.
  *  - return value: 0 ok, <0 invalid argument (CTK_E_*), >0 a hipError_t.
@@ -41,11 +46,15 @@ extern "C" {
 #endif
 
 /* ABI history (what a binding written against an older header must know):
+ *   v9 (round 6): + ctk_set_option / ctk_get_option (every back-end choice of the library in one validated, atomic table; the
+ *       environment variables are read ONCE when the library is loaded); - the two stream-K scratch entry points of v7 (the
+ *       stream-K walk of the persistent GEMMs left the library); ctk_gemm_pp_mode(m) = ctk_set_option(CTK_OPT_GEMM_PP, m) and
+ *       accepts bits 0 and 5 only; the release library has no debug switches and exports no ctk_debug_* symbol.
  *   v8 (round 4): + ctk_bilinear_sampler (Op D); ctk_window_args.flags must be 0 or CTK_WINDOW_NO_SPACE_ATTN -- unknown bits are
  *       CTK_E_SHAPE in every entry point taking the struct; ctk_probe_mfma kind 2; the *_workspace_bytes queries no longer include
- *       the stream-K scratch (~64 MiB) unless ctk_gemm_pp_mode bit 4 is set when they are called.
- *   v7: ctk_gemm_scratch_bytes / ctk_gemm_set_scratch.   v6: ctk_window_args.flags, the encoder entry points.   v5: CoTracker2 window. */
-#define CTK_ABI_VERSION 8
+ *       the stream-K scratch.
+ *   v7: ctk_gemm_scratch_bytes and its setter (removed in v9).   v6: ctk_window_args.flags, the encoder entry points.   v5: CoTracker2 window. */
+#define CTK_ABI_VERSION 9
 #define CTK_LEVELS 4
 #define CTK_C 128          /* latent_dim                       cotracker3_online.py:60  */
 #define CTK_TAPS 49        /* (2*corr_radius+1)^2, radius 3    build_cotracker.py:33    */
@@ -354,14 +363,6 @@ typedef struct ctk_gemm_args {
   int32_t c_split;         /* write C in SH format: ldc / c_bs count halves, ldc % 64 == 0, no resid; needs Wp */
 } ctk_gemm_args;
 int ctk_gemm(const ctk_gemm_args* g, void* stream);
-/* Stream-K scratch of the persistent split-half kernels (csrc/gemm_pp.hip).  With N = 384 and M = 102400 a Linear of the
- * path is 800 tiles on 256 CUs -- four rounds, the last 1/8 full -- unless the tiles' K ranges are dealt as one stream; the
- * two workgroups that then share a tile exchange one partial tile through this buffer (flags + one 256 KiB slot per CU).
- * ctk_forward_window / ctk_update_former[_ex] carve it from their own workspace; a bare ctk_gemm uses it only after
- * ctk_gemm_set_scratch(mem, bytes, stream) on the calling thread (mem = NULL takes it back).  Results with and without it
- * differ in the last bits (the K sum is split at a fixed, shape-dependent place: still deterministic). */
-int ctk_gemm_scratch_bytes(size_t* out_bytes);
-int ctk_gemm_set_scratch(void* mem, size_t bytes, void* stream);
 /* Split a torch-layout weight [N,K] (K % 32 == 0, row stride ldw) into the packed two-half form
  * the split-half back end reads: 64-byte header {s, 1/s} (s = power of two, chosen on the device
  * from max|W|) + [N][K/32][2][32] IEEE halves (hi, lo of s*W).  Done once per weight at load.   */
@@ -430,10 +431,43 @@ typedef struct ctk_profile_row {
   double bytes;
 } ctk_profile_row;
 int ctk_profile_enable(int on);
-/* Dev / A-B knob (process-global, not thread-safe): 1 (default) = the big split-half Linears (N % 256 == 0 or N % 192 == 0,
- * >= 128 tiles of 256 rows) run on the persistent ping-pong kernels of gemm_pp.hip, 0 = always gemm_f16x3.hip's kernels.
- * Bit 4 (stream-K, off by default) adds ~64 MiB of scratch to every *_workspace_bytes answer: a workspace sized before the bit was
- * set is too small afterwards (CTK_E_WORKSPACE) -- query again after changing it. */
+/* ---- back-end options ------------------------------------------------------------------
+ * Where the library holds two kernels for one operator, the choice is an OPTION: a process-wide table of validated integers
+ * (relaxed atomics: ctk_set_option may be called from any thread at any time; a launch uses the value it reads when it is
+ * enqueued).  The initial value of every option comes from its environment variable, read ONCE when the library is loaded --
+ * nothing in the library calls getenv() later.  No option changes what is computed: two back ends of one operator agree to the
+ * last-bit differences stated below.  Unknown keys / out-of-range values: CTK_E_SHAPE, nothing changes.
+ *   key                                env var            default  values
+ *   CTK_OPT_GEMM_PP                    CTK_GEMM_PP        33       bit 0: the big split-half Linears (N % 256 == 0 or N % 192 == 0, >= one
+ *                                                                  256-row tile per CU) run on the persistent ping-pong kernels of
+ *                                                                  csrc/gemm_pp.hip (0 = always gemm_f16x3.hip's kernels: same products, same
+ *                                                                  K order, bit-identical but for the residual Linears' last bit);
+ *                                                                  bit 5 (32): tail split -- a last round of tiles that would be <= TAIL_PCT %
+ *                                                                  full goes to the 64 x 64-tile kernel
+ *   CTK_OPT_GEMM_TAIL_PCT              CTK_GEMM_TAIL_PCT  25       0..100
+ *   CTK_OPT_CORR_VERSION               CTK_CORR           3        split-half correlation sampler: 3 = wave-owned footprint rows straight into
+ *                                                                  MFMA registers, 1 = the round-3 kernel (footprint through LDS, two barriers per
+ *                                                                  frame); same arithmetic, volumes agree to 3e-6
+ *   CTK_OPT_CORR_MAP                   CTK_CORR_MAP       3        workgroup -> (point, level) dealing of version 3: 3 = level-major (neighbouring
+ *                                                                  points of a grid query run together), 0 = point-major, 1 / 2 / 4 = pairs / blocks
+ *   CTK_OPT_ATTENTION_VALU             CTK_ATTN           0        1 = every attention shape on the VALU kernel (the fallback of the MFMA kernels)
+ *   CTK_OPT_ATTENTION_TIME_PERSISTENT  CTK_ATTN_TIME      1        0 = the non-persistent time-attention kernel (bit-identical)
+ *   CTK_OPT_OVERLAP                    CTK_OVERLAP        0        use of ctk_window_args.aux_stream: bit 0 = sampler of one point piece beside
+ *                                                                  corr_mlp of the previous one, bit 1 = the points<-virtual query projection
+ *                                                                  beside the virtual-track chain (bit-identical; measured <= 0.2 % either way) */
+enum {
+  CTK_OPT_GEMM_PP = 0,
+  CTK_OPT_GEMM_TAIL_PCT = 1,
+  CTK_OPT_CORR_VERSION = 2,
+  CTK_OPT_CORR_MAP = 3,
+  CTK_OPT_ATTENTION_VALU = 4,
+  CTK_OPT_ATTENTION_TIME_PERSISTENT = 5,
+  CTK_OPT_OVERLAP = 6,
+  CTK_OPT_COUNT = 7
+};
+int ctk_set_option(int key, int value);
+int ctk_get_option(int key, int* value);
+/* = ctk_set_option(CTK_OPT_GEMM_PP, mode), ignoring an invalid mode (the pre-v9 name) */
 void ctk_gemm_pp_mode(int mode);
 int ctk_profile_read(ctk_profile_row* rows, int max_rows, int* nrows);
 /* Register-only MFMA loop (2 workgroups x 4 waves per CU) to calibrate the sustained peak of this

@@ -41,3 +41,20 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture
+def ctk_option():
+    """set(key, value): a back-end option of the library (include/ctk.h: ctk_set_option) for the duration of one test."""
+    from cotracker_amd import _lib
+
+    stack = []
+
+    def set_(key, value):
+        o = _lib.option(key, value)
+        o.__enter__()
+        stack.append(o)
+
+    yield set_
+    for o in reversed(stack):
+        o.__exit__(None, None, None)

@@ -29,7 +29,44 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SYMBOLS), f"binding/header mismatch: {declared ^ set(_lib.SYMBOLS)}"
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.ctk_abi_version() == _lib.ABI_VERSION == 9
+
+
+def test_release_library_has_no_debug_symbols_and_only_documented_knobs(lib):
+    """Round 6: the library the package loads is a RELEASE build -- no ctk_debug_* entry point, no experiment
+    knob; the only CTK_* names inside it are the seven option variables include/ctk.h documents (read once at load)."""
+    import subprocess
+
+    from cotracker_amd import _lib
+    if os.path.basename(_lib.LIB_PATH) != "libctk_hip.so":
+        pytest.skip("CTK_LIB_PATH points at another build")
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln and ln.split()[-1].startswith("ctk_")}
+    assert exported == set(_lib.SYMBOLS), exported ^ set(_lib.SYMBOLS)
+    assert not [x for x in exported if "debug" in x]
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"CTK_[A-Z0-9_]{3,}", blob))
+    documented = {b"CTK_GEMM_PP", b"CTK_GEMM_TAIL_PCT", b"CTK_CORR", b"CTK_CORR_MAP", b"CTK_ATTN", b"CTK_ATTN_TIME", b"CTK_OVERLAP"}
+    assert names <= documented, names - documented
+    header = open(os.path.join(ROOT, "include", "ctk.h")).read()
+    for n in documented:
+        assert n.decode() in header
+
+
+def test_options_are_validated(lib):
+    from cotracker_amd import _lib as L
+    v = C.c_int(-1)
+    defaults = {L.OPT_GEMM_PP: 33, L.OPT_GEMM_TAIL_PCT: 25, L.OPT_CORR_VERSION: 3, L.OPT_CORR_MAP: 3, L.OPT_ATTENTION_VALU: 0,
+                L.OPT_ATTENTION_TIME_PERSISTENT: 1, L.OPT_OVERLAP: 0}
+    for k, d in defaults.items():
+        assert lib.ctk_get_option(k, C.byref(v)) == 0 and v.value == d, (k, v.value)
+    assert lib.ctk_get_option(0, None) == -1 and lib.ctk_get_option(7, C.byref(v)) == -2 and lib.ctk_get_option(-1, C.byref(v)) == -2
+    for k, bad in ((L.OPT_CORR_VERSION, 2), (L.OPT_CORR_VERSION, 0), (L.OPT_CORR_VERSION, 4), (L.OPT_CORR_MAP, 5), (L.OPT_ATTENTION_VALU, 2),
+                   (L.OPT_OVERLAP, 4), (L.OPT_OVERLAP, 8), (L.OPT_GEMM_TAIL_PCT, 101), (L.OPT_GEMM_PP, -1), (7, 0)):
+        assert lib.ctk_set_option(k, bad) == -2, (k, bad)
+    with L.option(L.OPT_CORR_VERSION, 1):
+        assert lib.ctk_get_option(L.OPT_CORR_VERSION, C.byref(v)) == 0 and v.value == 1
+    assert lib.ctk_get_option(L.OPT_CORR_VERSION, C.byref(v)) == 0 and v.value == 3
 
 
 def test_argument_validation_without_gpu(lib):

@@ -6,11 +6,18 @@ Every Linear flavour of the update path, at sizes that take the persistent path 
     first eight K-tiles of a tile and is added into the accumulators between MFMA phases; gemm_f16x3.hip adds it last);
   * with the TAIL SPLIT (mode bit 5, the default since round 5): the row blocks of a nearly empty last round go to the
     64 x 64-tile kernel -- rows are independent, so the bits must not depend on where the cut is;
-  * TIMING ROBUSTNESS: `ctk_gemm_pp_mode(9)` makes every wave sleep pseudo-random times around every barrier.  The LDS-DMA
-    ring / barrier protocol must not depend on timing, so the result has to stay bit-identical.  (This is the test that
-    found the round-3 race: a wave leaving its epilogue early issued LDS-DMA into a ring slot another wave of its group
-    was still using as store-transpose scratch -- invisible alone, garbage when a second process shared the GPU.)
+  * CONCURRENCY (round 6): two host threads launching on two streams at once -- the release library keeps no device-side or
+    host-side state a launch could trample on;
+  * TIMING ROBUSTNESS: in the DEV build (`make dev`, libctk_hip_dev.so) mode bit 3 makes every wave sleep pseudo-random times
+    around every barrier.  The LDS-DMA ring / barrier protocol must not depend on timing, so the result has to stay
+    bit-identical.  (This is the test that found the round-3 race: a wave leaving its epilogue early issued LDS-DMA into a ring
+    slot another wave of its group was still using as store-transpose scratch -- invisible alone, garbage when a second process
+    shared the GPU.)  The release library has no such switch: the jitter runs happen in a subprocess that loads the dev build.
 """
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
@@ -47,8 +54,7 @@ def _run(case, mode, data):
     return out
 
 
-@pytest.mark.parametrize("case", sorted(CASES))
-def test_gemm_pp_matches_fp64_old_kernels_and_survives_timing_jitter(case):
+def _make(case):
     from cotracker_amd import ops
     M, K, N, act, res, split, brows, bias = CASES[case]
     dev = torch.device("cuda:0")
@@ -59,7 +65,15 @@ def test_gemm_pp_matches_fp64_old_kernels_and_survives_timing_jitter(case):
     br = torch.randn(16, N, generator=g).to(dev) if brows else None
     r = (3 * torch.randn(M, N, generator=g)).to(dev) if res else None
     data = (ops.split_rows(a), w, ops.pack_weight(w), b, br, r)
+    return a, w, b, br, r, data
 
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_gemm_pp_matches_fp64_and_old_kernels(case):
+    from cotracker_amd import ops
+    M, K, N, act, res, split, brows, bias = CASES[case]
+    dev = torch.device("cuda:0")
+    a, w, b, br, r, data = _make(case)
     ref = a.double() @ w.double().t()
     if bias:
         ref += b.double()
@@ -84,68 +98,92 @@ def test_gemm_pp_matches_fp64_old_kernels_and_survives_timing_jitter(case):
         assert torch.equal(old, new)
     for _ in range(3):
         assert torch.equal(_run(case, 1, data), new), "persistent kernel is not deterministic"
-    for _ in range(3):
-        assert torch.equal(_run(case, 9, data), new), "result depends on wave timing: LDS-DMA / barrier protocol race"
-    # tail split: the last row blocks run as 64 x 64 tiles with the same compile-time epilogue -- same bits, also under jitter;
+    # tail split: the last row blocks run as 64 x 64 tiles with the same compile-time epilogue -- same bits;
     # with a residual the persistent kernel adds it into the accumulators and the 64 x 64 kernel last: a rounding apart
-    split, split_jit = _run(case, 33, data), _run(case, 41, data)
-    assert torch.equal(split, split_jit), "tail split + timing jitter changed the result"
+    cut = _run(case, 33, data)
+    assert torch.equal(cut, _run(case, 33, data))
     if res:
-        assert float((split.double() - ref).abs().max()) < tol
-        assert float((split - new).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
+        assert float((cut.double() - ref).abs().max()) < tol
+        assert float((cut - new).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
     else:
-        assert torch.equal(split, new), "tail split changed the result"
+        assert torch.equal(cut, new), "tail split changed the result"
 
 
-# Stream-K walk (ctk_gemm_pp_mode bit 4 + a lent scratch buffer, include/ctk.h: ctk_gemm_set_scratch): OFF by default --
-# measured gain 5 % on mlp.fc2 only, see gemm_pp.hip -- but it must stay correct: the two workgroups sharing a tile exchange
-# a partial tile through cache-bypassing stores / loads and per-wave flags.
-SK_CASES = ["to_q", "to_kv"]  # the linear f32 epilogues without residual (the only ones that take part; round 5: a
-# "+ residual" tile must start at K-tile 0, where its residual rides on the first K-tiles -- the tail split covers those Linears)
-
-
-@pytest.mark.parametrize("case", SK_CASES)
-def test_gemm_pp_stream_k_matches_rounds_is_deterministic_and_survives_jitter(case):
+def test_release_library_rejects_experiment_bits():
+    """include/ctk.h v9: the release build accepts bits 0 and 5 of CTK_OPT_GEMM_PP only (no 'no stores', no jitter, no stream-K)."""
     import ctypes as C
 
-    from cotracker_amd import _lib, ops
-    M, K, N, act, res, split, brows, bias = CASES[case]
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device="cpu").manual_seed(7 * K + N)
-    a = torch.randn(M, K, generator=g).to(dev)
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
-    b = torch.randn(N, generator=g).to(dev)
-    r = (3 * torch.randn(M, N, generator=g)).to(dev) if res else None
-    data = (ops.split_rows(a), w, ops.pack_weight(w), b, None, r)
-    ref = a.double() @ w.double().t() + b.double()
-    if res:
-        ref += r.double()
+    from cotracker_amd import _lib
     lib = _lib.load()
-    nbytes = C.c_size_t(0)
-    _lib.check(lib.ctk_gemm_scratch_bytes(C.byref(nbytes)), "ctk_gemm_scratch_bytes")
-    scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-    scratch.fill_(0xFF)  # stale partial tiles and garbage behind the flags must not matter
-    stream = torch.cuda.current_stream().cuda_stream
-    rounds = _run(case, 1, data)
-    try:
-        assert lib.ctk_gemm_set_scratch(None, 0, None) == 0
-        assert lib.ctk_gemm_set_scratch(C.c_void_p(scratch.data_ptr() + 4), nbytes.value, C.c_void_p(stream)) == -3  # CTK_E_ALIGN
-        assert lib.ctk_gemm_set_scratch(C.c_void_p(scratch.data_ptr()), nbytes.value - 1, C.c_void_p(stream)) == -4  # CTK_E_WORKSPACE
-        _lib.check(lib.ctk_gemm_set_scratch(C.c_void_p(scratch.data_ptr()), nbytes.value, C.c_void_p(stream)), "ctk_gemm_set_scratch")
-        sk = _run(case, 17, data)
-        tol = 4e-5 * max(1.0, float(ref.abs().max()) / 4)
-        assert float((sk.double() - ref).abs().max()) < tol
-        # the K sum of a shared tile is split at a fixed place: last-bit differences against the round walk, and some must
-        # exist (otherwise the walk was not taken: the shapes above have tiles % 256 != 0)
-        d = float((sk - rounds).abs().max())
-        assert 0.0 < d < tol
+    if os.path.basename(_lib.LIB_PATH) != "libctk_hip.so":
+        pytest.skip("running against a dev build")
+    cur = C.c_int(0)
+    for bad in (2, 8, 9, 16, 17, 64, 128, 256):
+        assert lib.ctk_set_option(_lib.OPT_GEMM_PP, bad) == -2
+        lib.ctk_gemm_pp_mode(bad)  # the pre-v9 name ignores an invalid mode
+        _lib.check(lib.ctk_get_option(_lib.OPT_GEMM_PP, C.byref(cur)), "ctk_get_option")
+        assert cur.value == 33
+    assert not hasattr(lib, "ctk_debug_pp_clock") and not hasattr(lib, "ctk_debug_pp_trace")
+
+
+def test_two_host_threads_two_streams_concurrently():
+    """SURVEY 8(b) "re-entrant": two host threads enqueue different Linears on two streams at the same time, many times; every
+    result equals the one the same call produces alone.  (Until round 5 every persistent launch wrote a device-side global,
+    g_pp_clock, and the sampler / attention launchers called getenv() per launch.)"""
+    import threading
+
+    from cotracker_amd import ops
+    cases = ["to_q", "to_kv"]
+    made = {c: _make(c) for c in cases}
+    alone = {c: _run(c, 33, made[c][5]) for c in cases}
+    errs = []
+
+    def worker(case):
+        try:
+            M, K, N, act, res, split, brows, bias = CASES[case]
+            a_sh, w, wp, b, br, r = made[case][5]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    out = ops.gemm(a_sh, w, bias=b, act=act, bias_rows=br, packed=wp, out_split=split)
+                    if not torch.equal(out, alone[case]):  # (synchronises this stream only)
+                        errs.append(f"{case}: result differs under concurrency")
+                        return
+        except Exception as e:  # noqa: BLE001
+            errs.append(f"{case}: {type(e).__name__}: {e}")
+
+    th = [threading.Thread(target=worker, args=(c,)) for c in cases]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+
+
+DEV_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "co-tracker_amd", "libctk_hip_dev.so")
+
+
+def _jitter_main():
+    """Runs in a subprocess with CTK_LIB_PATH = the dev build: every case with and without timing jitter (mode bit 3), with and
+    without the tail split; prints one line per case."""
+    from cotracker_amd import _lib
+    assert os.path.basename(_lib.LIB_PATH) == "libctk_hip_dev.so"
+    for case in sorted(CASES):
+        data = _make(case)[5]
+        plain, split = _run(case, 1, data), _run(case, 33, data)
         for _ in range(3):
-            assert torch.equal(_run(case, 17, data), sk), "stream-K walk is not deterministic"
-        for _ in range(3):
-            assert torch.equal(_run(case, 25, data), sk), "stream-K result depends on wave timing"
-        assert torch.equal(_run(case, 1, data), rounds)  # bit 4 clear: the scratch is ignored
-    finally:
-        lib.ctk_gemm_set_scratch(None, 0, None)
-        lib.ctk_gemm_pp_mode(33)
-    flags = scratch[:16384].view(torch.int32)
-    assert int(flags.abs().max()) == 0, "a flag was left raised"
+            assert torch.equal(_run(case, 9, data), plain), f"{case}: result depends on wave timing: LDS-DMA / barrier protocol race"
+        assert torch.equal(_run(case, 41, data), split), f"{case}: tail split + timing jitter changed the result"
+        print("jitter ok", case, flush=True)
+
+
+def test_gemm_pp_survives_timing_jitter_in_the_dev_build():
+    if not os.path.exists(DEV_LIB):
+        pytest.skip("libctk_hip_dev.so not built (make -C co-tracker_amd/csrc dev)")
+    env = dict(os.environ, CTK_LIB_PATH=DEV_LIB)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_gemm_pp as t; t._jitter_main()" % (root, os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("jitter ok") == len(CASES), out.stdout

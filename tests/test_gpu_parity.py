@@ -193,11 +193,11 @@ def test_layernorm(affine):
                                             (7, 48, 48, 1), (9, 8, 8, 1), (2, 64, 64, 1), (4, 64, 1500, 32),
                                             (3, 64, 6400, 7), (2, 1000, 64, 1), (11, 33, 33, 1), (3, 20, 50, 1)])
 @pytest.mark.parametrize("backend", ["mfma", "valu"])
-def test_attention(B, N1, N2, splits, backend, monkeypatch):
+def test_attention(B, N1, N2, splits, backend, ctk_option):
     """MFMA kernels (64-key, 64-query and square shapes; split-half products) and the exact-f32 VALU kernel
-    (CTK_ATTN=1, also the fallback for every other shape) against torch fp64."""
-    from cotracker_amd import ops
-    monkeypatch.setenv("CTK_ATTN", "1" if backend == "valu" else "0")
+    (CTK_OPT_ATTENTION_VALU, also the fallback for every other shape) against torch fp64."""
+    from cotracker_amd import _lib, ops
+    ctk_option(_lib.OPT_ATTENTION_VALU, 1 if backend == "valu" else 0)
     g = torch.Generator().manual_seed(B * 1000 + N1 + N2)
     q = torch.randn(B, N1, 384, generator=g).to(dev())
     k = torch.randn(B, N2, 384, generator=g).to(dev())
@@ -305,14 +305,14 @@ def test_corr_volume(golden, ops_model):
     assert maxdiff(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3]) == 0.0
 
 
-@pytest.mark.parametrize("version", ["1", "2", "3"])
-def test_corr_volume_sh(golden, ops_model, version, monkeypatch):
+@pytest.mark.parametrize("version", [1, 3])
+def test_corr_volume_sh(golden, ops_model, version, ctk_option):
     """Split-half sampler (footprint correlation on f16 MFMA x3, blend afterwards) vs the reference goldens.
     version 3 (the default since round 5) = footprint straight into the 16x16x32 MFMA's registers, one barrier per frame;
-    version 1 = the LDS-footprint kernel with two barriers per frame; version 2 = the wave-per-frame experiment with the blend
-    on MFMA (CTK_CORR selects)."""
-    from cotracker_amd import ops
-    monkeypatch.setenv("CTK_CORR", version)
+    version 1 = the LDS-footprint kernel with two barriers per frame (CTK_OPT_CORR_VERSION selects; version 2, the wave-per-frame
+    experiment, left the library in round 6)."""
+    from cotracker_amd import _lib, ops
+    ctk_option(_lib.OPT_CORR_VERSION, version)
     g = golden("ops")
     win = make_window(g, ops_model)
     S, N = win.S, win.N
@@ -330,13 +330,13 @@ def test_corr_volume_sh(golden, ops_model, version, monkeypatch):
     assert torch.equal(vol2[:, 1::3], vol.reshape(4, N, S, -1)[:, 1::3])
 
 
-@pytest.mark.parametrize("version", ["1", "2", "3"])
+@pytest.mark.parametrize("version", [1, 3])
 @pytest.mark.parametrize("S", [1, 2, 5, 20])
-def test_corr_volume_sh_stress_coordinates(S, version, monkeypatch):
+def test_corr_volume_sh_stress_coordinates(S, version, ctk_option):
     """Integer / half-integer / border / out-of-range coordinates (9-wide footprints, clamped taps), ragged frame
     chunks (S = 5: one short chunk; S = 20: 16 + 4) -- against the exact-f32 fused sampler (itself pinned to the goldens)."""
-    from cotracker_amd import ops
-    monkeypatch.setenv("CTK_CORR", version)
+    from cotracker_amd import _lib, ops
+    ctk_option(_lib.OPT_CORR_VERSION, version)
     r = np.random.RandomState(S)
     H0, W0, N = 48, 64, 90
     f0 = torch.from_numpy(r.standard_normal((S, H0, W0, 128)).astype(np.float32)).to(dev())
@@ -362,12 +362,17 @@ def test_corr_volume_sh_stress_coordinates(S, version, monkeypatch):
         assert maxdiff(ops.unsplit(got[l]), ref[l]) < 3e-6
 
 
-def test_corr_volume_sh_default_is_version_3_and_repeats_exactly(monkeypatch):
+def test_corr_volume_sh_default_is_version_3_and_repeats_exactly():
     """The default sampler is version 3, and -- interleaved with launches of the other versions, on rebuilt inputs, over many
     launches -- it returns the same bits every time.  (Round 5: an intermittent mismatch in lanes 48..63 of its blend came from
     a packed FMA with op_sel:[0,1,0] in front of an LDS write and showed only between other kernels' launches; tools/soak_corr.py
     is the long form of this test.)"""
-    from cotracker_amd import ops
+    import ctypes as C
+
+    from cotracker_amd import _lib, ops
+    cur = C.c_int(0)
+    _lib.check(_lib.load().ctk_get_option(_lib.OPT_CORR_VERSION, C.byref(cur)), "ctk_get_option")
+    assert cur.value == 3  # the library's default (no CTK_CORR in the test environment)
     S, H0, W0, N = 20, 48, 64, 90
     first = None
     for rep in range(12):
@@ -381,21 +386,21 @@ def test_corr_volume_sh_default_is_version_3_and_repeats_exactly(monkeypatch):
         sup = [ops.sample_support(pyr[l], torch.zeros(N, device=dev()), (coords[0] / 2 ** l).contiguous()) for l in range(4)]
         win = ops.Window(pyr, sup, coords, torch.zeros(S, N, device=dev()), torch.zeros(S, N, device=dev()), (W0, H0), iters=1)
         outs = {}
-        for version in ("1", "2", None, "3"):
-            if version is None:
-                monkeypatch.delenv("CTK_CORR", raising=False)
-            else:
-                monkeypatch.setenv("CTK_CORR", version)
+        for version in (1, None, 3):
             ops.corr_volume(win)  # (another kernel's LDS contents and timing in between, as in the stress test)
-            outs[version] = ops.corr_volume_sh(win).clone()
-        assert torch.equal(outs[None], outs["3"])          # unset == version 3
-        assert not torch.equal(outs["1"], outs["3"])       # (a different summation order: the versions are distinguishable)
+            if version is None:
+                outs[version] = ops.corr_volume_sh(win).clone()
+            else:
+                with _lib.option(_lib.OPT_CORR_VERSION, version):
+                    outs[version] = ops.corr_volume_sh(win).clone()
+        assert torch.equal(outs[None], outs[3])          # default == version 3
+        assert not torch.equal(outs[1], outs[3])         # (a different summation order: the versions are distinguishable)
         if first is None:
-            first = outs["3"]
+            first = outs[3]
             ref = ops.corr_volume(win)
             for l in range(4):
                 assert maxdiff(ops.unsplit(first[l]), ref[l]) < 3e-6
-        assert torch.equal(outs["3"], first), f"repetition {rep}"
+        assert torch.equal(outs[3], first), f"repetition {rep}"
 
 
 def test_corr_embed(golden, ops_model):
@@ -1136,15 +1141,14 @@ def test_full_size_properties(monkeypatch):
     for x, y in zip(a, c):
         assert maxdiff(x, y) == 0.0          # chunking of the correlation stage does not change results
     if precision_is_split(m):
-        for mode in ("1", "2", "3"):
-            monkeypatch.setenv("CTK_OVERLAP", mode)
+        from cotracker_amd import _lib
+        for mode in (1, 2, 3):
+            with _lib.option(_lib.OPT_OVERLAP, mode):
+                for x, y in zip(a, run(262144)):
+                    assert maxdiff(x, y) == 0.0  # corr pipeline / side q-projection / both, on the auxiliary stream
+        with _lib.option(_lib.OPT_ATTENTION_TIME_PERSISTENT, 0):
             for x, y in zip(a, run(262144)):
-                assert maxdiff(x, y) == 0.0  # corr pipeline / side q-projection / both, on the auxiliary stream
-        monkeypatch.delenv("CTK_OVERLAP")
-        monkeypatch.setenv("CTK_ATTN_TIME", "0")
-        for x, y in zip(a, run(262144)):
-            assert maxdiff(x, y) == 0.0      # persistent time-attention kernel == the one-job-per-wave kernel
-        monkeypatch.delenv("CTK_ATTN_TIME")
+                assert maxdiff(x, y) == 0.0      # persistent time-attention kernel == the one-job-per-wave kernel
     assert torch.isfinite(a[0]).all() and float((a[0] - qc[None]).abs().max()) > 1e-3
 
 
@@ -1154,11 +1158,11 @@ def test_full_size_properties(monkeypatch):
 @pytest.mark.parametrize("backend", ["mfma", "valu"])
 @pytest.mark.parametrize("B,N1,N2,splits,which", [(8, 64, 700, 3, "key"), (8, 300, 64, 1, "query"), (3, 64, 64, 1, "key"),
                                                    (5, 16, 16, 1, "key"), (2, 64, 256, 1, "all_keys_masked")])
-def test_attention_masks(B, N1, N2, splits, which, backend, monkeypatch):
+def test_attention_masks(B, N1, N2, splits, which, backend, ctk_option):
     """CrossAttnBlock's additive -FLT_MAX bias (cotracker.py:560-572): masked keys drop out, a masked query (or a
     row whose keys are all masked) attends uniformly."""
-    from cotracker_amd import ops
-    monkeypatch.setenv("CTK_ATTN", "1" if backend == "valu" else "0")
+    from cotracker_amd import _lib, ops
+    ctk_option(_lib.OPT_ATTENTION_VALU, 1 if backend == "valu" else 0)
     g = torch.Generator().manual_seed(B * 100 + N1 + N2)
     q = torch.randn(B, N1, 384, generator=g).to(dev())
     k = torch.randn(B, N2, 384, generator=g).to(dev())

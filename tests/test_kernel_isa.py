@@ -83,3 +83,51 @@ def test_no_kernel_stores_the_result_of_a_low_lane_op_sel_packed_op_right_behind
                     risky.append((os.path.basename(path), t, x))
                     break
     assert not risky, risky[:5]
+
+
+def _kernel_body(lines, pattern):
+    starts = [i for i, l in enumerate(lines) if re.match(pattern, l)]
+    assert len(starts) == 1, (pattern, len(starts))
+    end = next(i for i in range(starts[0], len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[starts[0]:end]
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
+@pytest.mark.parametrize("tag", [0, 1])
+def test_residual_loads_of_the_persistent_gemm_are_untouched_until_their_wait(tmp_path, tag):
+    """gemm_pp192_kernel<EPI = 36> ("+ residual": to_out, mlp.fc2) fetches the residual pieces with inline-asm
+    global_load_dwordx4 into plain "=v" outputs -- hipcc does not know the values are in flight until the hand-counted vmcnt one
+    phase later.  At 255 of 256 VGPRs a compiler-inserted copy, spill or reuse of those registers between the load and the wait
+    that retires it would store stale data silently.  This test reads the ISA: no scratch, and between every such load and the first
+    s_waitcnt whose vmcnt count retires it (loads retire in order: count <= VMEM operations issued behind it) no instruction
+    names its destination registers."""
+    asm = _compile_to_asm("gemm_pp", str(tmp_path))
+    text = open(asm).read()
+    lines = text.split("\n")
+    name = f"gemm_pp192_kernelILi36ELb0ELi{tag}E"
+    body = [l.strip() for l in _kernel_body(lines, rf"^_ZN.*{name}.*:") if l.startswith("\t") and not l.strip().startswith(";")]
+    m = re.search(rf"\.amdhsa_kernel _ZN[^\n]*{name}[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S)
+    assert m and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(1)), "the residual kernel must not use scratch"
+    loads = [i for i, t in enumerate(body) if re.match(r"global_load_dwordx4\s+v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*off\b", t)]
+    assert len(loads) == 25, len(loads)  # the bias staging loop of the prologue (compiler-visible) + 6 sub-tiles x 4 line pieces per tile
+    loads = loads[1:]
+    vmem = re.compile(r"(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|global_atomic)")
+    for i in loads:
+        d = re.match(r"global_load_dwordx4\s+v\[(\d+):(\d+)\]", body[i])
+        dest = set(range(int(d.group(1)), int(d.group(2)) + 1))
+        behind = 0
+        retired = False
+        for t in body[i + 1:i + 4000]:
+            w = re.match(r"s_waitcnt\b(.*)", t)
+            if w:
+                c = re.search(r"vmcnt\((\d+)\)", w.group(1))
+                if c and int(c.group(1)) <= behind:
+                    retired = True
+                    break
+                continue
+            if vmem.match(t):
+                behind += 1
+                if re.match(r"global_load_dwordx4\s+v\[", t) and (_regs(t.split(",")[0]) & dest):
+                    break  # the destination is re-used by the next sub-tile's load only behind the wait: handled by `retired`
+            assert not (_regs(t) & dest), f"{name}: `{t}` touches {sorted(dest)} of `{body[i]}` before the wait that retires it"
+        assert retired, f"{name}: no retiring wait found behind `{body[i]}`"

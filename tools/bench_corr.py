@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the correlation sampler alone on a C3-sized window (S=16, N=6400, 96x128 4-level pyramid).
-Versions 1, 2, 3 (CTK_CORR) and their bisection bits (CTK_CORR_DBG).  Env: REPS, NPTS, ONLY."""
+Versions 1 and 3 (CTK_OPT_CORR_VERSION), the workgroup dealings (CTK_OPT_CORR_MAP) and, in dev builds, the bisection bits (CTK_CORR_DBG).  Env: REPS, NPTS, ONLY."""
 import os
 import sys
 
@@ -22,21 +22,17 @@ coords = (q[None] + torch.arange(S)[:, None, None] * torch.tensor([0.13, 0.07]) 
 sup = [ops.sample_support(pyr[l], torch.zeros(N, device=dev), (coords[0] / 2 ** l).contiguous()) for l in range(4)]
 win = ops.Window(pyr, sup, coords, torch.zeros(S, N, device=dev), torch.zeros(S, N, device=dev), (W0, H0), iters=1)
 reps = int(os.environ.get("REPS", "10"))
-V2 = {"CTK_CORR": "2"}
-V3 = {"CTK_CORR": "3", "CTK_CORR_MAP": "0"}  # (the bisection rows below were taken with the point-major dealing)
-for tag, env in (("warmup", {}), ("v1", {"CTK_CORR": "1"}), ("v3", V3), ("v3_nostore", dict(V3, CTK_CORR_DBG="1")), ("v3_noloads", dict(V3, CTK_CORR_DBG="2")),
-                 ("v3_neither", dict(V3, CTK_CORR_DBG="3")), ("v3_nomfma", dict(V3, CTK_CORR_DBG="16")), ("v3_noblend", dict(V3, CTK_CORR_DBG="32")),
-                 ("v3_nomfma_noblend", dict(V3, CTK_CORR_DBG="48")), ("v3_nostorephase", dict(V3, CTK_CORR_DBG="64")),
-                 ("v3_loads_only", dict(V3, CTK_CORR_DBG="112")), ("v3_again", V3), ("v3_map1", dict(V3, CTK_CORR_MAP="1")), ("v3_map2", dict(V3, CTK_CORR_MAP="2")),
-                 ("v3_map1_noloads", dict(V3, CTK_CORR_MAP="1", CTK_CORR_DBG="2")), ("v3_map0_b", V3), ("default", {}), ("v3_map1_b", dict(V3, CTK_CORR_MAP="1")), ("v3_map2_b", dict(V3, CTK_CORR_MAP="2")), ("v3_map3", dict(V3, CTK_CORR_MAP="3")), ("v3_map4", dict(V3, CTK_CORR_MAP="4")), ("v3_map3_b", dict(V3, CTK_CORR_MAP="3")),
-                 ("v3_map4_b", dict(V3, CTK_CORR_MAP="4")), ("v3_map3_nostore", dict(V3, CTK_CORR_MAP="3", CTK_CORR_DBG="1")), ("v3_map3_noloads", dict(V3, CTK_CORR_MAP="3", CTK_CORR_DBG="2")), ("v1_b", {"CTK_CORR": "1"}), ("v2", V2), ("v2_nostore", dict(V2, CTK_CORR_DBG="1")),
-                 ("v2_noloads", dict(V2, CTK_CORR_DBG="2")), ("v2_neither", dict(V2, CTK_CORR_DBG="3")),
-                 ("v2_nt", dict(V2, CTK_CORR_DBG="4")), ("v2_nopf", dict(V2, CTK_CORR_DBG="8")), ("v1_again", {"CTK_CORR": "1"})):
+from cotracker_amd import _lib  # noqa: E402
+
+# rows: (tag, CTK_OPT_CORR_VERSION, CTK_OPT_CORR_MAP).  The bisection bits (CTK_CORR_DBG: no stores / no loads / no MFMAs ...) exist in
+# the DEV build only and are read once per process: `CTK_LIB_PATH=co-tracker_amd/libctk_hip_dev.so CTK_CORR_DBG=<bits> ONLY=v3 ...`
+for tag, ver, mp in (("warmup", 3, 3), ("v1", 1, 0), ("v3", 3, 0), ("v3_map1", 3, 1), ("v3_map2", 3, 2), ("v3_map3", 3, 3), ("v3_map4", 3, 4),
+                     ("default", None, None), ("v1_b", 1, 0), ("v3_map3_b", 3, 3)):
     if os.environ.get("ONLY") and tag not in os.environ["ONLY"].split(","):
         continue
-    for k in ("CTK_CORR", "CTK_CORR_DBG", "CTK_CORR_MAP"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    lib = _lib.load()
+    lib.ctk_set_option(_lib.OPT_CORR_VERSION, 3 if ver is None else ver)
+    lib.ctk_set_option(_lib.OPT_CORR_MAP, 3 if mp is None else mp)
     out = ops.corr_volume_sh(win)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

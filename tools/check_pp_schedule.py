@@ -14,7 +14,7 @@ def check(name, phases_per_kt, prologue, program, slot_of, ring_kt, KT=7, tiles=
     in-order vmcnt queue), an optional vmcnt value replacing the program's, and the (tile, i) whose loads this phase consumes
     (they must have been retired by a wait of an EARLIER phase of the same wave).  stores_per_tile: the epilogue's stores,
     which queue behind the DMA pieces issued before them (gfx9 has no vscnt).
-    issue_in_mma (round 5, template parameter DIM of the kernels): a phase's block is issued inside its MFMA burst, i.e. BEHIND the
+    issue_in_mma (the round-5 experiment that left the kernels in round 6; kept in the checker): a phase's block is issued inside its MFMA burst, i.e. BEHIND the
     phase's wait (and behind the extra loads of its load segment) instead of in front of it; the WAR rule is kept as for an issue
     in the load segment (the real issue is half a phase later: conservative)."""
     """program[p] = (reads, issue, wait) for phase p of K-tile J:
@@ -130,30 +130,3 @@ check("pp192_resid", 3,
       ([(0, "I0", 3), (0, "I1", 2), (0, "I2", 2), (1, "I0", 3)], 5),
       [(["I0", "I1"], (1, "I1", 2), 5), (["I2"], (1, "I2", 2), None), (["I2"], (2, "I0", 3), 5)],
       slot_of=lambda k: {"I0": 1, "I1": 2, "I2": 4}[k], ring_kt=2, KT=12, tiles=3, extra=_resid, stores_per_tile=24)
-
-
-# ---- DIM variants (ctk_gemm_pp_mode bit 7): every block issued inside the MFMA burst of its phase, behind that phase's wait
-all_kinds = ["A0", "B0", "B1", "A1"]
-check("pp256_dim", 4,
-      ([(0, "A0", 2), (0, "B0", 2), (0, "B1", 2), (0, "A1", 2), (1, "A0", 2), (1, "B0", 2)], 8),
-      [(["A0", "B0"], (1, "B1", 2), 6), (["B1"], (1, "A1", 2), 6), (["A1"], (2, "A0", 2), 6), ([], (2, "B0", 2), 6)],
-      slot_of=lambda k: {"A0": 1, "B0": 2, "B1": 4, "A1": 8}[k], ring_kt=2, KT=12, tiles=3, issue_in_mma=True)
-
-all_kinds = ["I0", "I1", "I2"]
-check("pp192_dim", 3,
-      ([(0, "I0", 3), (0, "I1", 2), (0, "I2", 2), (1, "I0", 3)], 5),
-      [(["I0", "I1"], (1, "I1", 2), 3), (["I2"], (1, "I2", 2), None), (["I2"], (2, "I0", 3), 2)],
-      slot_of=lambda k: {"I0": 1, "I1": 2, "I2": 4}[k], ring_kt=2, KT=12, tiles=3, issue_in_mma=True)
-
-
-def _resid_dim(i, p, tile):
-    n = 4 if (p == 1 and i <= 5) else 0
-    w = 6 if (p == 2 and i <= 5) else None
-    needs = (i - 1) if (p == 1 and 1 <= i <= 6) else None
-    return n, w, needs
-
-
-check("pp192_resid_dim", 3,
-      ([(0, "I0", 3), (0, "I1", 2), (0, "I2", 2), (1, "I0", 3)], 5),
-      [(["I0", "I1"], (1, "I1", 2), 3), (["I2"], (1, "I2", 2), None), (["I2"], (2, "I0", 3), 2)],
-      slot_of=lambda k: {"I0": 1, "I1": 2, "I2": 4}[k], ring_kt=2, KT=12, tiles=3, extra=_resid_dim, stores_per_tile=24, issue_in_mma=True)

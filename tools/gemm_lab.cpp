@@ -4,7 +4,8 @@
 //   2. checks BOTH against an fp64 host reference on sampled rows (incl. the last rows of a ragged M) and against each other,
 //   3. re-runs the new kernel several times and demands bit-identical output (an LDS race shows up as nondeterminism),
 //   4. times both, interleaved, with HIP events on the launch stream.
-// Build:  hipcc -O2 tools/gemm_lab.cpp -o tools/gemm_lab -Lco-tracker_amd -lctk_hip -Wl,-rpath,'$ORIGIN/../co-tracker_amd'
+// Build (against the DEV library, `make -C co-tracker_amd/csrc dev`: the trace / clock / jitter / no-store modes exist only there):
+//   hipcc -O2 -std=c++17 tools/gemm_lab.cpp -o tools/gemm_lab -Iinclude -Lco-tracker_amd -lctk_hip_dev -Wl,-rpath,'$ORIGIN/../co-tracker_amd'
 // Usage:  tools/gemm_lab [quick]   (quick: small shapes only, for a smoke run)
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -68,14 +69,9 @@ int main(int argc, char** argv) {
   hipStream_t st;
   HIP_OK(hipStreamCreate(&st));
   printf("ctk abi %d\n", ctk_abi_version());
-  // stream-K scratch for the persistent kernels (used by the modes with bit 4 = 16 set); LAB_OLD = the mode of the "old" column
+  // LAB_OLD / LAB_NEW = the ctk_gemm_pp_mode values of the "old" / "new" columns
   const int old_mode = getenv("LAB_OLD") ? atoi(getenv("LAB_OLD")) : 0;
   const int new_mode = getenv("LAB_NEW") ? atoi(getenv("LAB_NEW")) : 1;
-  size_t sk_bytes = 0;
-  CTK_OKAY(ctk_gemm_scratch_bytes(&sk_bytes));
-  void* sk_mem = nullptr;
-  HIP_OK(hipMalloc(&sk_mem, sk_bytes));
-  if (!getenv("LAB_NO_SK")) CTK_OKAY(ctk_gemm_set_scratch(sk_mem, sk_bytes, st));
 
   const bool dense = argc > 1 && (!strcmp(argv[1], "dense") || !strcmp(argv[1], "stress"));  // the shapes of tests/test_sharding.py's dense-mode run (S = 8, 3840 points)
   std::vector<Shape> shapes;

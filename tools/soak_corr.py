@@ -6,7 +6,7 @@ version in VERS (interleaved: each leaves its own LDS contents and timing behind
 
 Written in round 5 to corner an intermittent mismatch of version 3 (1 launch in ~30, only in the chunk's second frame, only
 lanes 48..63 of a wave, only the first register of a ds_write2_b32): a v_pk_fma_f32 with op_sel:[0,1,0] right in front of the
-LDS write.  profiles/r05_sampler_v3_pk_hazard.txt has the story.  Env: REPS (3), VERS ("1,2,3"), QUIET."""
+LDS write.  profiles/r05_sampler_v3_pk_hazard.txt has the story.  Env: REPS (3), VERS ("1,3"), QUIET."""
 import collections
 import os
 import sys
@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cotracker_amd import ops  # noqa: E402
+from cotracker_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 bad = 0
@@ -23,8 +23,8 @@ summary = {}
 launches = 0
 for rep in range(int(os.environ.get("REPS", "3"))):
     for S in (1, 2, 5, 20):
-        for version in os.environ.get("VERS", "1,2,3").split(","):
-            os.environ["CTK_CORR"] = version
+        for version in os.environ.get("VERS", "1,3").split(","):
+            _lib.load().ctk_set_option(_lib.OPT_CORR_VERSION, int(version))
             r = np.random.RandomState(S)
             H0, W0, N = 48, 64, 90
             f0 = torch.from_numpy(r.standard_normal((S, H0, W0, 128)).astype(np.float32)).to(dev)
