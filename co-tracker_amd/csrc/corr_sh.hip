@@ -647,6 +647,27 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
     //    grid_sampler_3d: (x0,y0),(x1,y0),(x0,y1),(x1,y1))
     if (BL) {
       float* dst = stgb + ((tl - 1) & 1) * CTK_CORR_LD + bpo * CTK_TAPS + bq0;
+#if defined(CTK_PK_NOP)
+      // Round-6 hazard experiment (tools/pk_nop_experiment.sh; never defined in a library build): the control flow of round 5's
+      // deterministic failing build (profiles/r05_sampler_v3_pk_hazard_variants.patch, CTK_CORR_DBG=8192: element-wise FMAs with
+      // the (w, w) pairs indexed crosswise -> hipcc emits v_pk_fma_f32 ... op_sel:[0,1,0] in front of ds_write2_b32), with
+      // the wait states themselves (s_nop) are inserted into the ISA by the tool's post-pass: any inline asm tied to the results makes
+      // hipcc drop the packed form, and one that is not tied is scheduled elsewhere.
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(c00)[j], b = reinterpret_cast<const f32x4*>(c10)[j];
+        const f32x4 c = reinterpret_cast<const f32x4*>(c01)[j], d = reinterpret_cast<const f32x4*>(c11)[j];
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(d[e], W11[e & 1], fmaf(c[e], W01[e & 1], fmaf(b[e], W10[e & 1], a[e] * W00[e & 1])));
+        if (bcnt == 12) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[4 * j + e] = o[e];
+        } else if (bcnt == 1 && j == 0) {
+          dst[0] = o[0];
+        }
+      }
+#else
       if (bcnt == 12) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -664,6 +685,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
       } else if (bcnt == 1) {  // q = 48
         dst[0] = fmaf(c11[0], W11[0], fmaf(c01[0], W01[0], fmaf(c10[0], W10[0], c00[0] * W00[0])));
       }
+#endif
     }
     __syncthreads();
   };

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 GPU session: tools/gpu_session.sh [pmc] [tests] [bench] [more] [prof] [sq] [lab] [retest]   (default: tests bench)
-# One gpurun call = one box: everything wanted from it is listed here; outputs go to gpurun_out/r05_*.
+# Round-6 GPU session: tools/gpu_session.sh [pmc] [tests] [bench] [more] [prof] [sq] [lab] [retest] [soak]   (default: tests bench)
+# One gpurun call = one box: everything wanted from it is listed here; outputs go to gpurun_out/r06_*.
 # The LAST call of a round runs "pmc tests bench more prof sq" on the final tree: profiles/pmc_traffic.json is stamped with the
 # hash of the kernel sources (__graft_entry__.source_hash), so any later edit under csrc/ makes it stale for bench.py.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=r05
+R=r06
 SRC_HASH=$(python -c "import __graft_entry__ as g; print(g.source_hash())")
 echo "kernel sources sha256 $SRC_HASH"
 WHAT="${*:-tests bench}"
@@ -39,9 +39,13 @@ if has pmc; then
   head -30 gpurun_out/${R}_pmc_traffic.txt
   cp gpurun_out/${R}_pmc_traffic.json profiles/pmc_traffic.json  # (on the box: the bench lines below attach it; its library hash is this build's)
 fi
-if has lab; then  # GEMM lab: fp64 / determinism / timing of every Linear shape, the shader clock under load, the wave timeline
+if has lab; then  # GEMM lab (linked against the DEV library): fp64 / determinism / timing of every Linear shape, the shader clock under load
   (timeout 600 tools/gemm_lab 2>&1 | tail -20) | tee gpurun_out/${R}_gemm_lab.log
   (timeout 200 tools/gemm_lab clock 33 2>&1 | tail -10) | tee gpurun_out/${R}_gemm_clock.log
+fi
+if has soak; then  # production-shape soak of the default sampler (C3 window, 2000 launches, bitwise) + the stress-window soak of both versions
+  (timeout 900 env WINDOW=c3 LAUNCHES=${SOAK_LAUNCHES:-2000} python tools/soak_corr.py 2>&1 | tail -6) | tee gpurun_out/${R}_soak_corr_c3.log
+  (timeout 900 env REPS=24 QUIET=1 python tools/soak_corr.py 2>&1 | tail -6) | tee gpurun_out/${R}_soak_corr_stress.log
 fi
 if has tests; then
   timeout 2400 python -m pytest tests -m gpu -q --durations=8 --tb=short > gpurun_out/${R}_pytest_gpu_full.log 2>&1

@@ -18,6 +18,43 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cotracker_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("WINDOW") == "c3":
+    # Production-shape soak: the C3 window -- S = 16 frames, N = 6400 grid points on the 96 x 128 level-0 map,
+    # 25 600 workgroups per launch -- LAUNCHES (2000) launches of the DEFAULT sampler, each compared bit for bit with the first
+    # (and the first with the exact-f32 sampler to 3e-6); other kernels (the compare, a pyramid rebuild every 50 launches) run in
+    # between, as in a real step.  Exit code 1 on any mismatch.
+    S, H0, W0, G = 16, 96, 128, 80
+    N = G * G
+    n_launch = int(os.environ.get("LAUNCHES", "2000"))
+    r = np.random.RandomState(7)
+    f0 = torch.from_numpy(r.standard_normal((S, H0, W0, 128)).astype(np.float32)).to(dev)
+    f0 = (f0 / f0.norm(dim=-1, keepdim=True)).contiguous()
+    pyr = ops.build_pyramid(f0)
+    ys, xs = np.meshgrid(np.linspace(3, H0 - 4, G), np.linspace(3, W0 - 4, G), indexing="ij")
+    q = np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(np.float32)
+    c = q[None] + np.arange(S)[:, None, None] * np.array([0.13, 0.07], np.float32) + 0.3 * r.uniform(size=(S, N, 2)).astype(np.float32)
+    c[:, ::97] = np.round(c[:, ::97])  # some integer coordinates: 9-wide footprints
+    coords = torch.from_numpy(c.astype(np.float32)).to(dev)
+    sup = [ops.sample_support(pyr[l], torch.zeros(N, device=dev), (coords[0] / 2 ** l).contiguous()) for l in range(4)]
+    win = ops.Window(pyr, sup, coords, torch.zeros(S, N, device=dev), torch.zeros(S, N, device=dev), (W0, H0), iters=1)
+    first = ops.corr_volume_sh(win).clone()
+    ref = ops.corr_volume(win)
+    worst = max(float((ops.unsplit(first[l]) - ref[l]).abs().max()) for l in range(4))
+    del ref
+    mism = []
+    for i in range(n_launch):
+        if i % 50 == 49:
+            pyr = ops.build_pyramid(f0)  # same values, fresh buffers: other kernels and allocations in between
+            win = ops.Window(pyr, sup, coords, torch.zeros(S, N, device=dev), torch.zeros(S, N, device=dev), (W0, H0), iters=1)
+        out = ops.corr_volume_sh(win)
+        if not torch.equal(out, first):
+            d = (out.view(torch.int16) != first.view(torch.int16)).nonzero()
+            mism.append((i, int(d.shape[0]), d[:4].tolist()))
+            print(f"launch {i}: {d.shape[0]} halves differ, first at {d[:4].tolist()}", flush=True)
+        del out
+    print(f"soak c3 window: S={S} N={N} ({N * 4} workgroups per launch), {n_launch} launches of the default sampler, "
+          f"first launch vs exact-f32 sampler max {worst:.3g}; launches that differ bitwise from the first: {len(mism)}")
+    sys.exit(1 if mism or worst >= 3e-6 else 0)
 bad = 0
 summary = {}
 launches = 0
