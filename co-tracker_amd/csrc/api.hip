@@ -10,9 +10,9 @@
 
 int ctk_launch_corr_volume(const ctk_window_args* a, int n0, int ncount, float* out, long level_stride, int ld,
                            hipStream_t s);
-int ctk_launch_pyramid_split(const float* fmap, long pixels, void* out, hipStream_t s);
+int ctk_launch_pyramid_split(const float* fmap, long pixels, void* out, int version, hipStream_t s);
 int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh, int n0, int ncount, void* out,
-                              long level_stride_halves, hipStream_t s);
+                              long level_stride_halves, int version, hipStream_t s);
 int ctk_launch_virtual_init(const float* vt, int S, float* dst, hipStream_t s);
 int ctk_launch_layernorm2(const float* x, void* y, long R, const float* gamma, const float* beta, float eps, void* y2, float eps2,
                           int out_split, hipStream_t s);
@@ -348,6 +348,7 @@ struct CorrWs {
   void* fm_sh[CTK_LEVELS];  // split mode: SH copy of the window's pyramid (scaled by 2^8), [S*H*W][4][2][32] halves
   size_t bytes;
   int chunk;
+  int corr_version;  // CTK_OPT_CORR_VERSION as read ONCE per entry-point call: the layout of fm_sh and the sampler kernel must agree
 };
 
 int corr_chunk_points(const ctk_window_args* a) {
@@ -358,6 +359,7 @@ int corr_chunk_points(const ctk_window_args* a) {
 
 CorrWs carve_corr(const ctk_window_args* a, void* base) {
   CorrWs w;
+  w.corr_version = ctk_opt(CTK_OPT_CORR_VERSION);
   w.chunk = corr_chunk_points(a);
   const size_t rows = (size_t)w.chunk * a->S;
   char* p = static_cast<char*>(base);
@@ -379,7 +381,7 @@ int prepare_pyramid_sh(const ctk_window_args* a, const CorrWs& ws, hipStream_t s
   for (int l = 0; l < CTK_LEVELS; ++l) {
     if (!a->fmaps[l]) return CTK_E_NULL;
     if (a->H[l] <= 0 || a->W[l] <= 0) return CTK_E_SHAPE;
-    CTK_TRY(ctk_launch_pyramid_split(a->fmaps[l], (long)a->S * a->H[l] * a->W[l], ws.fm_sh[l], s));
+    CTK_TRY(ctk_launch_pyramid_split(a->fmaps[l], (long)a->S * a->H[l] * a->W[l], ws.fm_sh[l], ws.corr_version, s));
   }
   return CTK_OK;
 }
@@ -409,7 +411,7 @@ int run_corr_embed(const ctk_window_args* a, const ctk_model_weights* w, float* 
       float* vol = ws.vol + (size_t)p0 * a->S * CTK_LEVELS * CTK_CORR_LD;
       float* h1 = ws.h1 + (size_t)p0 * a->S * CTK_LEVELS * CTK_HID;
       hipStream_t gs = s;
-      if (sp) CTK_TRY(ctk_launch_corr_volume_sh(a, ws.fm_sh, n0 + p0, pc, vol, rows * CTK_CORR_LD * 2, s));
+      if (sp) CTK_TRY(ctk_launch_corr_volume_sh(a, ws.fm_sh, n0 + p0, pc, vol, rows * CTK_CORR_LD * 2, ws.corr_version, s));
       else CTK_TRY(ctk_launch_corr_volume(a, n0 + p0, pc, vol, rows * CTK_CORR_LD, CTK_CORR_LD, s));
       if (pipelined && pieces > 1) {
         CTK_TRY(pipe.fork());
@@ -534,7 +536,7 @@ extern "C" int ctk_corr_volume_sh(const ctk_window_args* a, void* out, void* wor
   if (ws.bytes > workspace_bytes) return CTK_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   CTK_TRY(prepare_pyramid_sh(a, ws, s));
-  return ctk_launch_corr_volume_sh(a, ws.fm_sh, 0, a->N, out, (long)a->N * a->S * CTK_CORR_LD * 2, s);
+  return ctk_launch_corr_volume_sh(a, ws.fm_sh, 0, a->N, out, (long)a->N * a->S * CTK_CORR_LD * 2, ws.corr_version, s);
 }
 
 // Workspace of a whole window: x | update-former buffers | correlation buffers

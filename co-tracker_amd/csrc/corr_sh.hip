@@ -57,7 +57,8 @@ static_assert(SUP_BYTES + 15 * 128 <= C_BYTES + STG_BYTES1, "the support image (
 static_assert(2 * LDS1_BYTES <= 160 * 1024, "two workgroups per CU");
 
 struct CorrShP {
-  const _Float16* fm[CTK_LEVELS];  // SH pyramid of the window: [S][H][W][4][2][32] halves, scaled by 2^8
+  const _Float16* fm[CTK_LEVELS];  // SH pyramid of the window, scaled by 2^8: [S][H][W][4][2][32] halves (version 1) or eight planes [4][2][S][H][W][32] (version 3)
+  long plane[CTK_LEVELS];          // halves per plane of the version-3 layout (S * H * W * 32)
   const float* support[CTK_LEVELS];
   int H[CTK_LEVELS], W[CTK_LEVELS];
   float sx[CTK_LEVELS], sy[CTK_LEVELS];
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
   const float sx = p.sx[lvl], sy = p.sy[lvl];
   const float inv = 1.0f / (float)(1 << lvl);  // coords / 2**i : exact
   const _Float16* fm = p.fm[lvl];
+  const long plane = p.plane[lvl];
   // ---- prologue (as version 1): coordinates -> LDS; support patch -> split, scaled, swizzled image; tap tables ----
   if (tid < 2 * nt) cxy[tid] = p.coords[((long)(t0 + (tid >> 1)) * p.N + n) * 2 + (tid & 1)];
   {
@@ -530,15 +532,15 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
     fy -= (fy * fw > r);
     fy += ((fy + 1) * fw <= r);
     const int fx = r - fy * fw;
-    const _Float16* px = fm + (((long)(t0 + tl) * H + tab->yb + fy) * W + tab->xb + fx) * (2 * CTK_C) + g4 * 8;
+    const _Float16* px = fm + (((long)(t0 + tl) * H + tab->yb + fy) * W + tab->xb + fx) * 32 + g4 * 8;  // plane 0 (K-tile 0, hi) of my pixel
     if (DBG & 2) px = fm + g4 * 8;
     // (Compiler-managed loads.  Inline-asm loads with counted waits that leave the three younger volume stores in flight were
     // tried: not faster, and not safe -- nothing documents that a store cannot retire before an older load, so vmcnt(N) must
     // not be used to skip stores.)
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      ah[kt] = *reinterpret_cast<const f16x8*>(px + kt * 64);
-      al[kt] = *reinterpret_cast<const f16x8*>(px + kt * 64 + 32);
+      ah[kt] = *reinterpret_cast<const f16x8*>(px + (2 * kt) * plane);
+      al[kt] = *reinterpret_cast<const f16x8*>(px + (2 * kt + 1) * plane);
     }
   };
   // C[pixel][tap] of one row tile -> table Cw (f32, [88][60]; the 49 tap columns only).  Between two MFMAs on the same
@@ -698,8 +700,13 @@ __global__ __launch_bounds__(256, 2) void corr_volume_sh3_kernel(CorrShP p) {
   for (; tl <= nt + 1; ++tl) step(tl, true, tl <= nt, false);
 }
 
-// f32 rows -> SH with a power-of-two scale (pyramid conversion)
-__global__ void split_rows_scaled_kernel(const float* x, long n4, float scale, _Float16* out) {
+// f32 rows -> SH with a power-of-two scale (pyramid conversion).  PLANES = false: the SH row format [pixel][4 K-tiles][hi | lo][32]
+// (version 1 reads a pixel's 512 contiguous bytes); PLANES = true (version 3, round 6): eight planes [K-tile][hi | lo][pixel][32] of
+// 64 bytes per pixel -- the 16 lanes x 4 k-groups of one of version 3's fragment loads then read the 64-byte pieces of 16
+// CONSECUTIVE pixels (two footprint rows of 8: two contiguous 512-byte runs = 8-10 cache lines) instead of 64 bytes out of each of
+// 16 different 512-byte pixel records (16 lines, half of each used).
+template <bool PLANES>
+__global__ void split_rows_scaled_kernel(const float* x, long n4, float scale, _Float16* out, long plane_halves) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of a [*,128] matrix
   if (i >= n4) return;
   f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
@@ -707,20 +714,33 @@ __global__ void split_rows_scaled_kernel(const float* x, long n4, float scale, _
   f16x4 hi, lo;
   ctk_split4(v, hi, lo);
   const long k = i * 4;
-  _Float16* dst = out + (k >> 5) * 64 + (k & 31);
-  *reinterpret_cast<f16x4*>(dst) = hi;
-  *reinterpret_cast<f16x4*>(dst + 32) = lo;
+  if (PLANES) {
+    const long pix = k >> 7;
+    const int c = (int)(k & 127), kt = c >> 5;
+    _Float16* dst = out + (long)(2 * kt) * plane_halves + pix * 32 + (c & 31);
+    *reinterpret_cast<f16x4*>(dst) = hi;
+    *reinterpret_cast<f16x4*>(dst + plane_halves) = lo;
+  } else {
+    _Float16* dst = out + (k >> 5) * 64 + (k & 31);
+    *reinterpret_cast<f16x4*>(dst) = hi;
+    *reinterpret_cast<f16x4*>(dst + 32) = lo;
+  }
 }
 
 }  // namespace
 
 
-// SH copy (scaled by 2^8) of one pyramid level of the window: f32 NHWC [S,H,W,128] -> halves [S*H*W][4][2][32]
-int ctk_launch_pyramid_split(const float* fmap, long pixels, void* out, hipStream_t s) {
+// SH copy (scaled by 2^8) of one pyramid level of the window: f32 NHWC [S,H,W,128] -> halves [S*H*W][4][2][32] (sampler version 1)
+// or [4][2][S*H*W][32] (version 3).  `version` must be the one later handed to ctk_launch_corr_volume_sh for this copy.
+int ctk_launch_pyramid_split(const float* fmap, long pixels, void* out, int version, hipStream_t s) {
   const long n4 = pixels * (CTK_C / 4);
   CtkProfScope ps("pyramid_split", 0.0, 8.0 * 4.0 * n4, s);
-  hipLaunchKernelGGL(split_rows_scaled_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, fmap, n4, FSCALE,
-                     static_cast<_Float16*>(out));
+  if (version == 3)
+    hipLaunchKernelGGL(split_rows_scaled_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, fmap, n4, FSCALE,
+                       static_cast<_Float16*>(out), pixels * 32);
+  else
+    hipLaunchKernelGGL(split_rows_scaled_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, fmap, n4, FSCALE,
+                       static_cast<_Float16*>(out), 0L);
   CTK_HIP_CHECK_LAUNCH();
   return CTK_OK;
 }
@@ -728,7 +748,7 @@ int ctk_launch_pyramid_split(const float* fmap, long pixels, void* out, hipStrea
 // Correlation volumes of points [n0, n0+ncount) in SH format: out[l][(n-n0)*S + t][2*CTK_CORR_LD halves].
 // fm_sh[l] = ctk_launch_pyramid_split of a->fmaps[l].
 int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh, int n0, int ncount, void* out,
-                              long level_stride_halves, hipStream_t s) {
+                              long level_stride_halves, int version, hipStream_t s) {
   if (!a || !out) return CTK_E_NULL;
   if (a->S <= 0 || a->N <= 0) return CTK_E_SHAPE;
   CorrShP p;
@@ -740,6 +760,7 @@ int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh
     p.support[l] = a->support[l];
     p.H[l] = a->H[l];
     p.W[l] = a->W[l];
+    p.plane[l] = (long)a->S * a->H[l] * a->W[l] * 32;
     p.sx[l] = ctk_sampler_scale(a->W[l]);
     p.sy[l] = ctk_sampler_scale(a->H[l]);
   }
@@ -765,7 +786,7 @@ int ctk_launch_corr_volume_sh(const ctk_window_args* a, const void* const* fm_sh
   // so the second one finds the lines in L1 / L2): 2.47 -> 2.25 ms per launch at the C3 window; 0 = point-major (levels innermost,
   // the order of version 1), 1 / 2 = point pairs, 4 = blocks of 16 points (profiles/r05_sampler_v3_bisect.txt).
   p.map = ctk_opt(CTK_OPT_CORR_MAP);
-  const int v = ctk_opt(CTK_OPT_CORR_VERSION);
+  const int v = version;  // (the caller read CTK_OPT_CORR_VERSION once, for the pyramid copy and for this launch)
   if (v == 3) {
 #ifdef CTK_DEV
     // dev build only (make dev): CTK_CORR_DBG = bisection bits of version 3 (they change the RESULT: tools/bench_corr.py)
