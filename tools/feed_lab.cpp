@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512) void feed_kernel(P g) {
 
 // ---- second kernel: LDS-DMA only, ONE stream over all of the workgroup's K-tiles (no drain at tile boundaries), A requested
 // PD K-tiles ahead (ring of PD + 1 A slots), W one K-tile ahead (2 slots); stream order = order of need (W(g+1), A(g+PD)).
-template <int PD, int AON, int WON, int FRAG, int MF, int AUX, int NBLK = 3>
+template <int PD, int AON, int WON, int FRAG, int MF, int AUX, int NBLK = 3, int BLK = 0>
 __global__ __launch_bounds__(512) void feed2_kernel(P g) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[163840];
   constexpr int WBASE = (PD + 1) * 32768;
@@ -356,14 +356,14 @@ __global__ __launch_bounds__(512) void feed2_kernel(P g) {
     c.q = q;
     c.kt = 0;
     c.lim = (unsigned)min(255, g.M - 1 - mb * 256);
-    c.a = g.A + (long)mb * 256 * lda_b;
+    c.a = g.A + (long)mb * 256 * lda_b;  // (BLK: the row block's KT x 32 KiB are contiguous too: same base)
     c.w = g.W + (long)nb * 192 * ldw_b;
     return c;
   };
   auto cur_next = [&](Cur& c) {
     if (c.kt + 1 < KT) {
       c.kt += 1;
-      c.a += 128;
+      c.a += BLK ? 32768 : 128;
       c.w += 128;
     } else if (c.q + 1 < my_tiles) {
       c = cur_at(c.q + 1);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512) void feed2_kernel(P g) {
     for (int e = 0; e < 4; ++e) {
       const int piece = 4 * wave + e;
       const unsigned r = min((unsigned)(8 * piece) + l3, c.lim);
-      __builtin_amdgcn_global_load_lds((gptr_t)(c.a + r * lda_b + ((l7 ^ ((4 * piece + l4) & 7)) << 4)), (lptr_t)(dst + piece * 1024), 16, 0, AUX);
+      __builtin_amdgcn_global_load_lds((gptr_t)(c.a + r * (BLK ? 128u : lda_b) + ((l7 ^ ((4 * piece + l4) & 7)) << 4)), (lptr_t)(dst + piece * 1024), 16, 0, AUX);
     }
   };
   auto issue_w = [&](const Cur& c, const int slot) {
@@ -530,6 +530,8 @@ int main(int argc, char** argv) {
       V2(1, 1, 1, 0, 0, 0), V2(2, 1, 1, 0, 0, 0), V2(2, 1, 1, 0, 0, 2),
       V2(1, 1, 1, 1, 0, 0), V2(2, 1, 1, 1, 0, 0),
       V2(1, 1, 1, 1, 1, 0), V2(2, 1, 1, 1, 1, 0), V2(2, 1, 1, 1, 1, 2), V2(1, 0, 0, 0, 1, 0),
+#define V2B(PD, A, W, FR, MF) { "feed2 BLOCKED-A PD" #PD " A" #A " W" #W " frag" #FR " mfma" #MF, feed2_kernel<PD, A, W, FR, MF, 0, 3, 1>, A, W, FR, MF }
+      V2B(1, 1, 0, 0, 0), V2B(2, 1, 0, 0, 0), V2B(1, 1, 1, 0, 0), V2B(1, 1, 1, 1, 0), V2B(1, 1, 1, 1, 1), V2B(2, 1, 1, 1, 1),
       V2(1, 0, 0, 1, 1, 0), V2(1, 1, 1, 0, 1, 0), V2(1, 1, 0, 0, 1, 0), V2(1, 0, 1, 0, 1, 0), V2(1, 0, 1, 1, 1, 0), V2(1, 1, 0, 1, 1, 0),
   };
   printf("feed_lab M=%d K=%d tiles=%d (256x192) on %d CUs, %d reps\n", M, K, tiles, cus, reps);
