@@ -24,7 +24,7 @@ NAME_MAP = [
     (r"gemm_pp256_kernel<40,", "gemm_sh_pp256_k384_n256"),
     (r"gemm_pp192_kernel<41,", "gemm_sh_pp192_k2432_n384"),
     (r"gemm_pp192_kernel<16,", "gemm_sh_pp192_k1120_n384"),
-    (r"gemm_pp192_kernel<36, false, 1,", "gemm_sh_pp192_k1536_n384"),  # (round 5: a fourth template argument DIM follows TAG)
+    (r"gemm_pp192_kernel<36, false, 1>", "gemm_sh_pp192_k1536_n384"),  # (TAG = 1: K > 768; round 6 removed the fourth template argument)
     (r"gemm_pp192_kernel<36,", "gemm_sh_pp192_k384_n384"),
     (r"gemm_pp192_kernel<32,", "gemm_sh_pp192_k384_n384"),
     (r"gemm_sh_deep64_kernel", "gemm_sh_64x64"),
