@@ -411,6 +411,31 @@ __global__ __launch_bounds__(512) void feed2_kernel(P g) {
     BARRIER();
     const unsigned char* sa_ = lds + aslot * 32768;
     const unsigned char* sw_ = lds + WBASE + (gk & 1) * (NBLK * 8192);
+    if (NBLK == 6 && FRAG && MF) {
+      // register-lean order for the 256 x 384 tile (192 accumulators): per k-step j the A fragments of j only (16 registers) against
+      // all six column blocks, B fragments per (n, j) (8 registers); per accumulator the MFMA order is unchanged (j outer, term inner)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f16x8 a0[2], a1[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          a0[p] = *reinterpret_cast<const f16x8*>(sa_ + (wm * 64 + r32) * 128 + (((p * 4 + j * 2 + half) ^ fsw) << 4));
+          a1[p] = *reinterpret_cast<const f16x8*>(sa_ + (wm * 64 + 32 + r32) * 128 + (((p * 4 + j * 2 + half) ^ fsw) << 4));
+        }
+#pragma unroll
+        for (int n = 0; n < NBLK; ++n) {
+          f16x8 b[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            b[p] = *reinterpret_cast<const f16x8*>(sw_ + n * 8192 + (wn * 32 + r32) * 128 + (((p * 4 + j * 2 + half) ^ fsw) << 4));
+#pragma unroll
+          for (int term = 0; term < 3; ++term) {
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[term == 0 ? 1 : 0], a0[term == 1 ? 1 : 0], acc[0][n], 0, 0, 0);
+            acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[term == 0 ? 1 : 0], a1[term == 1 ? 1 : 0], acc[1][n], 0, 0, 0);
+          }
+        }
+      }
+    } else {
     if (FRAG) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -448,6 +473,7 @@ __global__ __launch_bounds__(512) void feed2_kernel(P g) {
             for (int mi = 0; mi < 2; ++mi) xacc ^= __builtin_bit_cast(u32x4, fa[mi][j][p]).y;
           }
       }
+    }
     }
     BARRIER();
     aslot = aslot == PD ? 0 : aslot + 1;
